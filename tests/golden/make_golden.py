@@ -1,0 +1,197 @@
+"""Generate the golden fixtures in this directory from the REAL reference (build container only).
+
+    python tests/golden/make_golden.py            # needs /root/reference, writes tests/golden/*.json
+
+Two kinds of fixture:
+  * ``unit_vectors.json`` — known-answer vectors for the pure functions of
+    /root/reference/src/cigar_parsing.py and /root/reference/src/breakpoint_utilities.py, obtained by
+    importing those modules unmodified and calling them on seeded random inputs;
+  * ``e2e_<config>[_variant].json`` — phase-by-phase snapshots (A2..A11 of SURVEY.md §8(a)) and the
+    emitted ``*_graph.txt`` / ``*_breakpoints.txt`` text of the reference's graph build run on the
+    synthetic records of ``coral_amd.synth.named_config(<config>)`` behind the fake pysam / cvxopt of
+    oracle/refharness (see there for what that does and does not pin).
+
+The fixtures are data (inputs are re-generated from the seeded generator and verified against the
+stored sha256); nothing of the reference's source text is stored.
+"""
+import json
+import os
+import random
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF_SRC = "/root/reference/src"
+
+E2E_CASES = [
+    ("tiny", []),
+    ("tiny", ["--output_bp"]),
+    ("tiny", ["--min_bp_support", "30.0"]),
+    ("small", []),
+    ("ultra", []),
+]
+
+
+def jsonable(o):
+    if isinstance(o, (set, frozenset)):
+        return {"__set__": sorted((jsonable(x) for x in o), key=lambda v: json.dumps(v))}
+    if isinstance(o, tuple):
+        return {"__tuple__": [jsonable(x) for x in o]}
+    if isinstance(o, list):
+        return [jsonable(x) for x in o]
+    if isinstance(o, dict):
+        return {"__dict__": [[jsonable(k), jsonable(v)] for k, v in o.items()]}
+    return o
+
+
+def unit_vectors():
+    sys.path.insert(0, REF_SRC)
+    import cigar_parsing as cp
+    import breakpoint_utilities as bu
+    rnd = random.Random(20241024)
+    out = {}
+
+    # ---- cigar2pos* (cp:17-215) through the dispatch dict (cp:219-229)
+    v = []
+    for pat in cp.cigar2pos_ops:
+        for strand in "+-":
+            for _ in range(6):
+                rl = rnd.randint(2000, 60000)
+                nums = [rnd.randint(1, rl // 3) for _ in pat]
+                cigar = "".join("%d%s" % (n, c) for n, c in zip(nums, pat))
+                v.append(dict(cigar=cigar, strand=strand, read_length=rl,
+                              out=list(cp.cigar2pos_ops[pat](cigar, strand, rl))))
+    out["cigar2pos"] = v
+
+    # ---- alignment_from_satags (cp:232-269)
+    chroms = ["chr7", "chr8", "chr12", "chrX"]
+    v = []
+
+    def rand_sa(rl, allow_bad=False):
+        pat = rnd.choice(list(cp.cigar2pos_ops))
+        if allow_bad and rnd.random() < 0.15:
+            pat = rnd.choice(["M", "MD", "MI"])
+        nums = [rnd.randint(1, rl // 3) for _ in pat]
+        cigar = "".join("%d%s" % (n, c) for n, c in zip(nums, pat))
+        return "%s,%d,%s,%s,%d,%d" % (rnd.choice(chroms), rnd.randint(1, 10 ** 8), rnd.choice("+-"), cigar,
+                                      rnd.randint(0, 60), rnd.randint(0, 500))
+    for k in range(40):
+        rl = rnd.randint(3000, 50000)
+        sa = [rand_sa(rl, allow_bad=(k % 5 == 4)) for _ in range(rnd.randint(2, 5))]
+        v.append(dict(sa_list=sa, read_length=rl, out=jsonable(cp.alignment_from_satags(list(sa), rl))))
+    out["alignment_from_satags"] = v
+
+    # ---- interval predicates (bu:11-67)
+    v = []
+    for _ in range(60):
+        a = ["chr8", rnd.randint(0, 1000), 0]; a[2] = a[1] + rnd.randint(-50, 400)
+        b = [rnd.choice(["chr8", "chr8", "chr7"]), rnd.randint(0, 1000), 0]; b[2] = b[1] + rnd.randint(-50, 400)
+        v.append(dict(a=a, b=b, overlap=bu.interval_overlap(a, b), include=bu.interval_include(a, b),
+                      adjacent=bu.interval_adjacent(a, b)))
+    out["interval_predicates"] = v
+    v = []
+    for _ in range(40):
+        a = ["chr8", rnd.randint(0, 2000), 0, -1]; a[2] = a[1] + rnd.randint(10, 1500)
+        L = []
+        for _ in range(rnd.randint(0, 5)):
+            s = rnd.randint(0, 3000)
+            L.append([rnd.choice(["chr8", "chr8", "chr12"]), s, s + rnd.randint(5, 900), rnd.randint(0, 3)])
+        ov, rem = bu.interval_exclusive(a, L)
+        v.append(dict(a=a, L=L, overlap_ints=sorted(ov), remaining=rem))
+    out["interval_exclusive"] = v
+
+    # ---- interval2bp (bu:289-295)
+    def rand_rint():
+        c = rnd.choice(chroms[:3]); s = rnd.randint(10 ** 6, 10 ** 7); e = s + rnd.randint(500, 20000)
+        return [c, s, e, "+"] if rnd.random() < 0.5 else [c, e, s, "-"]
+    v = []
+    for _ in range(60):
+        r1, r2 = rand_rint(), rand_rint()
+        gap = rnd.randint(-200, 300)
+        v.append(dict(R1=r1, R2=r2, r=["rd", 1, 2], rgap=gap, out=jsonable(bu.interval2bp(r1, r2, ("rd", 1, 2), gap))))
+    out["interval2bp"] = v
+
+    # ---- alignment2bp (bu:70-96) and alignment2bp_l (bu:129-186)
+    def rand_chimeric(intervals):
+        n = rnd.randint(2, 5)
+        qint, rint, qual = [], [], []
+        q = 0
+        for _ in range(n):
+            ln = rnd.randint(400, 6000)
+            q0 = q + rnd.randint(-150, 60)
+            qint.append([max(0, q0), max(0, q0) + ln])
+            q = qint[-1][1] + 1
+            iv = rnd.choice(intervals)
+            if rnd.random() < 0.8:
+                s = rnd.randint(iv[1], max(iv[1], iv[2] - ln - 1)); e = s + ln + rnd.randint(-30, 30)
+            else:
+                s = rnd.randint(10 ** 6, 10 ** 7); e = s + ln
+            rint.append([iv[0], s, e, "+"] if rnd.random() < 0.5 else [iv[0], e, s, "-"])
+            qual.append(rnd.choice([60, 60, 60, 30, 15, 5, 0]))
+        return (qint, rint, qual)
+    v, v2 = [], []
+    for k in range(80):
+        ivs = [["chr8", 2 * 10 ** 6, 2 * 10 ** 6 + 300000, 0], ["chr8", 4 * 10 ** 6, 4 * 10 ** 6 + 200000, 0],
+               ["chr12", 5 * 10 ** 6, 5 * 10 ** 6 + 250000, 1]]
+        ca = rand_chimeric(ivs)
+        i1, i2 = rnd.choice(ivs), rnd.choice(ivs)
+        v.append(dict(ca=jsonable(ca), i1=i1, i2=i2,
+                      out=jsonable(bu.alignment2bp("rd%d" % k, ca, 100, 20, i1[:3], i2))))
+        v2.append(dict(ca=jsonable(ca), intervals=ivs,
+                       out=jsonable(bu.alignment2bp_l("rd%d" % k, ca, 100, 20, 100, ivs))))
+    out["alignment2bp"] = v
+    out["alignment2bp_l"] = v2
+
+    # ---- cluster_bp_list (bu:252-286), bpc2bp (bu:299-388), bp_match (bu:391-416)
+    def rand_bp_list(n):
+        centres = [(rnd.choice(chroms[:2]), rnd.randint(10 ** 6, 10 ** 7), rnd.choice("+-"),
+                    rnd.choice(chroms[:2]), rnd.randint(10 ** 6, 10 ** 7), rnd.choice("+-")) for _ in range(4)]
+        L = []
+        for i in range(n):
+            c = rnd.choice(centres)
+            sp = rnd.choice([3, 3, 40, 1500, 2500])
+            L.append([c[0], c[1] + rnd.randint(-sp, sp), c[2], c[3], c[4] + rnd.randint(-sp, sp), c[5],
+                      ("rd%d" % i, rnd.randint(0, 2), rnd.randint(1, 3)), rnd.randint(-90, 400), rnd.randint(0, 1),
+                      rnd.choice([60, 60, 25]), rnd.choice([60, 60, 30])])
+        return L
+    v, v2 = [], []
+    for _ in range(25):
+        L = rand_bp_list(rnd.randint(1, 40))
+        cl = bu.cluster_bp_list(L, 3, 2000)
+        v.append(dict(bp_list=jsonable(L), min_cluster_size=3, cutoff=2000, out=jsonable(cl)))
+        for c in cl:
+            if len(c) >= 2:
+                bp, bpr, st, rem = bu.bpc2bp(c, 100)
+                v2.append(dict(cluster=jsonable(c), cutoff=100, bp=jsonable(bp), bpr=jsonable(bpr), stats=st,
+                               rest=jsonable(rem)))
+    out["cluster_bp_list"] = v
+    out["bpc2bp"] = v2
+    v = []
+    for _ in range(120):
+        c = ("chr8", rnd.randint(10 ** 6, 10 ** 6 + 500), rnd.choice("+-"), "chr8", rnd.randint(10 ** 6, 10 ** 6 + 500),
+             rnd.choice("+-"))
+        b1 = list(c)
+        b2 = [c[0], c[1] + rnd.randint(-400, 400), rnd.choice([c[2], c[2], "+"]), c[3], c[4] + rnd.randint(-400, 400), c[5]]
+        rgap = rnd.choice([0, -5, 30, 150, 600]) * rnd.choice([1.0, 1.2])
+        v.append(dict(bp1=b1, bp2=b2, rgap=rgap, cutoff=[100, 100], out=bool(bu.bp_match(b1, b2, rgap, [100, 100]))))
+    out["bp_match"] = v
+    return out
+
+
+def main():
+    assert os.path.isdir(REF_SRC), "the reference is only available in the build container"
+    with open(os.path.join(HERE, "unit_vectors.json"), "w") as fp:
+        json.dump(unit_vectors(), fp, separators=(",", ":"))
+    env = dict(os.environ, PYTHONHASHSEED="0")
+    for cfg, extra in E2E_CASES:
+        tag = cfg + "".join("_" + x.strip("-").replace(".", "p") for x in extra)
+        out = os.path.join(HERE, "e2e_%s.json" % tag)
+        cmd = [sys.executable, "-m", "oracle.refharness.run_reference", cfg, out] + extra
+        print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, cwd=ROOT, env=env, check=True, stdout=subprocess.DEVNULL)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
