@@ -113,9 +113,12 @@ def unit_vectors():
     out["interval2bp"] = v
 
     # ---- alignment2bp (bu:70-96) and alignment2bp_l (bu:129-186)
+    used = []
+
     def rand_chimeric(intervals):
         n = rnd.randint(2, 5)
         qint, rint, qual = [], [], []
+        del used[:]
         q = 0
         for _ in range(n):
             ln = rnd.randint(400, 6000)
@@ -128,14 +131,18 @@ def unit_vectors():
             else:
                 s = rnd.randint(10 ** 6, 10 ** 7); e = s + ln
             rint.append([iv[0], s, e, "+"] if rnd.random() < 0.5 else [iv[0], e, s, "-"])
-            qual.append(rnd.choice([60, 60, 60, 30, 15, 5, 0]))
+            qual.append(rnd.choice([60, 60, 60, 60, 60, 30, 15, 5, 0]))
+            used.append(iv)
         return (qint, rint, qual)
     v, v2 = [], []
-    for k in range(80):
+    for k in range(240):
         ivs = [["chr8", 2 * 10 ** 6, 2 * 10 ** 6 + 300000, 0], ["chr8", 4 * 10 ** 6, 4 * 10 ** 6 + 200000, 0],
                ["chr12", 5 * 10 ** 6, 5 * 10 ** 6 + 250000, 1]]
         ca = rand_chimeric(ivs)
         i1, i2 = rnd.choice(ivs), rnd.choice(ivs)
+        if k % 3:
+            j = rnd.randrange(len(used) - 1)
+            i1, i2 = (used[j], used[j + 1]) if k % 2 else (used[j + 1], used[min(j + 2, len(used) - 1)])
         v.append(dict(ca=jsonable(ca), i1=i1, i2=i2,
                       out=jsonable(bu.alignment2bp("rd%d" % k, ca, 100, 20, i1[:3], i2))))
         v2.append(dict(ca=jsonable(ca), intervals=ivs,
