@@ -1,0 +1,60 @@
+"""ctypes binding of libcoral_hip.so (include/coral_hip.h).  Fails loudly when the library is missing:
+there is no CPU fallback on the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcoral_hip.so")
+
+
+class CoralHipError(RuntimeError):
+    pass
+
+
+class coral_records_t(C.Structure):
+    _fields_ = [("n_rec", C.c_int64), ("tid", C.c_void_p), ("pos", C.c_void_p), ("end", C.c_void_p),
+                ("flagmq", C.c_void_p), ("n_cigar", C.c_void_p), ("cigar_off", C.c_void_p), ("cigar", C.c_void_p)]
+
+
+_lib = None
+
+# every symbol include/coral_hip.h declares (checked by tests/test_cabi.py)
+SYMBOLS = ["coral_version", "coral_last_error", "coral_cigar_scan", "coral_segment_coverage", "coral_point_cover",
+           "coral_read_counter", "coral_time_cigar_scan", "coral_bam_decode_open", "coral_bam_decode_sizes",
+           "coral_bam_decode_fill", "coral_bam_decode_close", "coral_cluster_first_fit"]
+
+
+def lib():
+    """Load (once) and return the shared library; raise CoralHipError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CoralHipError("libcoral_hip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "— the product path has no CPU fallback" % LIB_PATH)
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise CoralHipError("cannot load %s: %s" % (LIB_PATH, e))
+    L.coral_version.restype = C.c_char_p
+    L.coral_last_error.restype = C.c_char_p
+    P = C.c_void_p
+    R = C.POINTER(coral_records_t)
+    L.coral_cigar_scan.argtypes = [R, C.c_int32, C.c_int32, P, P, P, P, P, P, C.c_uint32, P]
+    L.coral_time_cigar_scan.argtypes = [R, C.c_int32, C.c_int32, P, P, P, P, P, P, C.c_uint32, C.c_int32,
+                                        C.POINTER(C.c_float), P]
+    L.coral_segment_coverage.argtypes = [R, P, P, C.c_int32, P, P, P, P, P, P, P, P]
+    L.coral_point_cover.argtypes = [R, C.c_int32, P, P, P, P, C.c_uint32, P]
+    L.coral_read_counter.argtypes = [P, C.POINTER(C.c_uint32), P]
+    for name in ("coral_cigar_scan", "coral_time_cigar_scan", "coral_segment_coverage", "coral_point_cover",
+                 "coral_read_counter"):
+        getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise CoralHipError("%s failed (%d): %s" % (what, rc, lib().coral_last_error().decode()))

@@ -1,0 +1,443 @@
+// coral_kernels.hip — gfx950 (MI355X, CDNA4) kernels behind include/coral_hip.h.
+//
+// All of this is integer / indexing work bounded by HBM bandwidth (no MFMA): 64-lane waves stream
+// 16-byte CIGAR quads (1 KiB per wave-instruction), wave-level scans give every op its reference
+// offset, ballot + popcount compaction emits the rare candidates, and integer atomics (order-free,
+// hence bit-exact) reduce per-segment sums.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/coral_hip.h"
+
+#define WAVE 64
+#define SCAN_BLOCK 256          // 4 waves per workgroup
+#define OP_PAD_QUAD 0x0000000Fu // op 15, length 0: consumes nothing
+
+// op classes as bit masks over the BAM op code (MIDNSHP=X are 0..8; 15 = layout padding)
+#define MASK_REF 0x18Du   // M D N = X advance the reference
+#define MASK_ALN 0x181u   // M = X are aligned blocks (pysam get_blocks / count_coverage)
+#define MASK_QRY 0x1B3u   // M I S H = X count towards infer_read_length()
+
+static thread_local char g_err[512] = "";
+
+static int set_err(int code, const char *msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+static int hip_err(hipError_t e, const char *what) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return CORAL_ERR_HIP;
+}
+
+extern "C" const char *coral_version(void) { return "coral_hip 0.1 (gfx950)"; }
+extern "C" const char *coral_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------------
+// wave helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_incl_scan_add(int x, int lane) {
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+
+__device__ __forceinline__ int wave_reduce_add(int x) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d);
+    return x;
+}
+
+__device__ __forceinline__ long long wave_reduce_add64(long long x) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d);
+    return x;
+}
+
+__device__ __forceinline__ int wave_reduce_min(int x) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) x = min(x, __shfl_xor(x, d));
+    return x;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1  cigar_scan — one wave per record, 256 ops (1 KiB) per wave-iteration, next chunk prefetched
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan(
+    long long n_rec, const int32_t *__restrict__ pos, const int32_t *__restrict__ flagmq,
+    const int32_t *__restrict__ n_cigar, const int64_t *__restrict__ cigar_off,
+    const uint32_t *__restrict__ cigar, int min_gap, int min_mapq, int32_t *__restrict__ mbases,
+    int32_t *__restrict__ qinfer, int32_t *__restrict__ blk_first, int32_t *__restrict__ blk_last,
+    int32_t *__restrict__ gaps, uint32_t *__restrict__ gap_count, uint32_t gap_cap) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * (SCAN_BLOCK / WAVE) + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * (SCAN_BLOCK / WAVE);
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const uint4 pad = make_uint4(OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD);
+
+    for (long long r = wave; r < n_rec; r += nwaves) {
+        const int n = n_cigar[r];
+        const int nq = (n + 3) >> 2;
+        const uint4 *__restrict__ q = reinterpret_cast<const uint4 *>(cigar + cigar_off[r]);
+        const int p0 = pos[r];
+        const bool gaps_on = ((flagmq[r] >> 16) & 0xff) >= min_mapq;
+
+        int carry_ref = 0;   // reference bases consumed by earlier chunks
+        int carry_end = 0;   // end (relative, >= 1) of the last aligned block seen so far; 0 = none
+        int msum = 0, qsum = 0, first = 0x7fffffff;
+
+        uint4 cur = pad;
+        if (lane < nq) cur = q[lane];
+        for (int c = 0; c < nq; c += WAVE) {
+            uint4 nxt = pad;
+            if (c + WAVE + lane < nq) nxt = q[c + WAVE + lane];   // prefetch the next KiB
+
+            const uint32_t v[4] = {cur.x, cur.y, cur.z, cur.w};
+            int len[4], adv[4];
+            bool aln[4];
+            int tot = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t op = v[k] & 15u;
+                len[k] = (int)(v[k] >> 4);
+                adv[k] = ((MASK_REF >> op) & 1u) ? len[k] : 0;
+                aln[k] = (MASK_ALN >> op) & 1u;
+                qsum += ((MASK_QRY >> op) & 1u) ? len[k] : 0;
+                tot += adv[k];
+            }
+            const int incl = wave_incl_scan_add(tot, lane);
+            int ref = carry_ref + incl - tot;      // reference offset of this lane's first op
+            // end of the last aligned block inside this lane (0 = none)
+            int lane_end = 0;
+            {
+                int rr = ref;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (aln[k]) lane_end = rr + len[k];
+                    rr += adv[k];
+                }
+            }
+            // previous aligned block end as seen by this lane's first aligned op
+            const unsigned long long has = __ballot(lane_end != 0);
+            const unsigned long long lower = has & below;
+            const int src = lower ? (63 - __clzll(lower)) : 0;
+            const int from_lane = __shfl(lane_end, src);
+            int prev = lower ? from_lane : carry_end;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (aln[k]) {
+                    if (prev > 0 && gaps_on && ref - prev > min_gap) {
+                        const uint32_t slot = atomicAdd(gap_count, 1u);
+                        if (slot < gap_cap) {
+                            int4 row = make_int4((int)r, (c + lane) * 4 + k, p0 + prev, p0 + ref);
+                            reinterpret_cast<int4 *>(gaps)[slot] = row;
+                        }
+                    }
+                    first = min(first, ref);
+                    prev = ref + len[k];
+                    msum += len[k];
+                }
+                ref += adv[k];
+            }
+            carry_ref += __shfl(incl, 63);
+            carry_end = __shfl(prev, 63);
+            cur = nxt;
+        }
+        msum = wave_reduce_add(msum);
+        qsum = wave_reduce_add(qsum);
+        first = wave_reduce_min(first);
+        if (lane == 0) {
+            mbases[r] = msum;
+            qinfer[r] = qsum;
+            blk_first[r] = (carry_end > 0) ? p0 + first : -1;
+            blk_last[r] = (carry_end > 0) ? p0 + carry_end : -1;
+        }
+    }
+}
+
+static int scan_grid(long long n_rec) {
+    long long blocks = (n_rec + (SCAN_BLOCK / WAVE) - 1) / (SCAN_BLOCK / WAVE);
+    const long long cap = 256 * 8;   // 256 CUs x 8 workgroups of 4 waves = 32 waves per CU
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+static int check_records(const coral_records_t *rec) {
+    if (!rec) return set_err(CORAL_ERR_ARG, "records: null");
+    if (rec->n_rec < 0 || rec->n_rec > 0x7fffffffLL) return set_err(CORAL_ERR_ARG, "records: n_rec out of range");
+    if (rec->n_rec > 0 && (!rec->tid || !rec->pos || !rec->end || !rec->flagmq || !rec->n_cigar || !rec->cigar_off || !rec->cigar))
+        return set_err(CORAL_ERR_ARG, "records: null array");
+    if (((uintptr_t)rec->cigar) & 15u) return set_err(CORAL_ERR_ARG, "records: cigar base must be 16-byte aligned");
+    return CORAL_OK;
+}
+
+extern "C" int coral_cigar_scan(const coral_records_t *rec, int32_t min_gap, int32_t min_mapq,
+                                int32_t *mbases, int32_t *qinfer, int32_t *blk_first, int32_t *blk_last,
+                                int32_t *gaps, uint32_t *gap_count, uint32_t gap_cap, void *stream) {
+    int rc = check_records(rec);
+    if (rc) return rc;
+    if (rec->n_rec == 0) return CORAL_OK;
+    if (!mbases || !qinfer || !blk_first || !blk_last || !gap_count || (gap_cap && !gaps))
+        return set_err(CORAL_ERR_ARG, "cigar_scan: null output");
+    if (((uintptr_t)gaps) & 15u) return set_err(CORAL_ERR_ARG, "cigar_scan: gaps must be 16-byte aligned");
+    hipLaunchKernelGGL(k_cigar_scan, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
+                       (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
+                       (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_err(e, "cigar_scan launch");
+    return CORAL_OK;
+}
+
+extern "C" int coral_time_cigar_scan(const coral_records_t *rec, int32_t min_gap, int32_t min_mapq,
+                                     int32_t *mbases, int32_t *qinfer, int32_t *blk_first, int32_t *blk_last,
+                                     int32_t *gaps, uint32_t *gap_count, uint32_t gap_cap, int32_t iters,
+                                     float *ms_per_launch, void *stream) {
+    if (!ms_per_launch || iters < 1) return set_err(CORAL_ERR_ARG, "time_cigar_scan: bad arguments");
+    hipEvent_t a, b;
+    hipError_t e = hipEventCreate(&a);
+    if (e != hipSuccess) return hip_err(e, "hipEventCreate");
+    e = hipEventCreate(&b);
+    if (e != hipSuccess) return hip_err(e, "hipEventCreate");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = CORAL_OK;
+    (void)hipEventRecord(a, s);
+    for (int i = 0; i < iters && rc == CORAL_OK; ++i) {
+        (void)hipMemsetAsync(gap_count, 0, sizeof(uint32_t), s);
+        rc = coral_cigar_scan(rec, min_gap, min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap, stream);
+    }
+    (void)hipEventRecord(b, s);
+    e = hipEventSynchronize(b);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    if (rc) return rc;
+    if (e != hipSuccess) return hip_err(e, "time_cigar_scan");
+    *ms_per_launch = ms / (float)iters;
+    return CORAL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2  segment coverage
+//   phase A (thread per record): classify against the sorted disjoint segment table; records fully
+//            inside one segment add mbases; boundary-straddling records are compacted into a list;
+//   phase B (wave per straddler): walk the CIGAR once per overlapped segment.
+// ---------------------------------------------------------------------------------------------
+#define COV_BLOCK 256
+#define COV_LDS_SEGS 2048
+
+__device__ __forceinline__ int first_seg_ending_after(const int32_t *__restrict__ seg_tid,
+                                                      const int32_t *__restrict__ seg_end, int n_seg, int tid, int p) {
+    // first j with (seg_tid[j], seg_end[j]) > (tid, p)
+    int lo = 0, hi = n_seg;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int t = seg_tid[mid];
+        const bool gt = (t > tid) || (t == tid && seg_end[mid] > p);
+        if (gt) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(COV_BLOCK) void k_seg_classify(
+    long long n_rec, const int32_t *__restrict__ tid, const int32_t *__restrict__ pos,
+    const int32_t *__restrict__ end, const int32_t *__restrict__ flagmq, const int32_t *__restrict__ n_cigar,
+    const int32_t *__restrict__ mbases, const int32_t *__restrict__ qinfer, int n_seg,
+    const int32_t *__restrict__ seg_tid, const int32_t *__restrict__ seg_start, const int32_t *__restrict__ seg_end,
+    unsigned long long *__restrict__ n_reads, unsigned long long *__restrict__ n_bases,
+    uint32_t *__restrict__ strad, uint32_t *__restrict__ strad_count) {
+    __shared__ unsigned long long bins[2 * COV_LDS_SEGS];
+    const bool use_lds = n_seg <= COV_LDS_SEGS;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < 2 * n_seg; i += COV_BLOCK) bins[i] = 0ull;
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const long long stride = (long long)gridDim.x * COV_BLOCK;
+    const long long n_round = (n_rec + stride - 1) / stride * stride;   // keep whole waves in the loop for ballots
+    for (long long r = (long long)blockIdx.x * COV_BLOCK + threadIdx.x; r < n_round; r += stride) {
+        bool is_strad = false;
+        if (r < n_rec) {
+            const int t = tid[r], p = pos[r], e = end[r];
+            int j = (t >= 0) ? first_seg_ending_after(seg_tid, seg_end, n_seg, t, p) : n_seg;
+            if (j < n_seg && seg_tid[j] == t && seg_start[j] < e) {
+                const bool counts = qinfer[r] > 0;
+                const bool has_seq = ((flagmq[r] >> 24) & 1) && n_cigar[r] > 0;
+                if (seg_start[j] <= p && e <= seg_end[j]) {
+                    if (use_lds) {
+                        if (counts) atomicAdd(&bins[2 * j], 1ull);
+                        if (has_seq) atomicAdd(&bins[2 * j + 1], (unsigned long long)mbases[r]);
+                    } else {
+                        if (counts) atomicAdd(&n_reads[j], 1ull);
+                        if (has_seq) atomicAdd(&n_bases[j], (unsigned long long)mbases[r]);
+                    }
+                } else {
+                    for (; j < n_seg && seg_tid[j] == t && seg_start[j] < e; ++j) {
+                        if (counts) {
+                            if (use_lds) atomicAdd(&bins[2 * j], 1ull); else atomicAdd(&n_reads[j], 1ull);
+                        }
+                    }
+                    is_strad = has_seq;
+                }
+            }
+        }
+        const unsigned long long m = __ballot(is_strad);
+        if (m) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(strad_count, (uint32_t)__popcll(m));
+            base = __shfl(base, 0);
+            if (is_strad) {
+                const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+                strad[base + __popcll(m & below)] = (uint32_t)r;
+            }
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_seg; i += COV_BLOCK) {
+            const unsigned long long a = bins[2 * i], b = bins[2 * i + 1];
+            if (a) atomicAdd(&n_reads[i], a);
+            if (b) atomicAdd(&n_bases[i], b);
+        }
+    }
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_seg_walk(
+    const uint32_t *__restrict__ strad, const uint32_t *__restrict__ strad_count,
+    const int32_t *__restrict__ tid, const int32_t *__restrict__ pos, const int32_t *__restrict__ end,
+    const int32_t *__restrict__ n_cigar, const int64_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar,
+    int n_seg, const int32_t *__restrict__ seg_tid, const int32_t *__restrict__ seg_start,
+    const int32_t *__restrict__ seg_end, unsigned long long *__restrict__ n_bases) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * (SCAN_BLOCK / WAVE) + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * (SCAN_BLOCK / WAVE);
+    const long long n_strad = *strad_count;
+    const uint4 pad = make_uint4(OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD);
+    for (long long w = wave; w < n_strad; w += nwaves) {
+        const long long r = strad[w];
+        const int t = tid[r], p0 = pos[r], e0 = end[r];
+        const int nq = (n_cigar[r] + 3) >> 2;
+        const uint4 *__restrict__ q = reinterpret_cast<const uint4 *>(cigar + cigar_off[r]);
+        int j = first_seg_ending_after(seg_tid, seg_end, n_seg, t, p0);
+        for (; j < n_seg && seg_tid[j] == t && seg_start[j] < e0; ++j) {
+            const int s = seg_start[j] - p0, e = seg_end[j] - p0;    // segment in record-relative coordinates
+            long long acc = 0;
+            int carry_ref = 0;
+            for (int c = 0; c < nq && carry_ref < e; c += WAVE) {
+                uint4 cur = pad;
+                if (c + lane < nq) cur = q[c + lane];
+                const uint32_t v[4] = {cur.x, cur.y, cur.z, cur.w};
+                int len[4], adv[4];
+                bool aln[4];
+                int tot = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t op = v[k] & 15u;
+                    len[k] = (int)(v[k] >> 4);
+                    adv[k] = ((MASK_REF >> op) & 1u) ? len[k] : 0;
+                    aln[k] = (MASK_ALN >> op) & 1u;
+                    tot += adv[k];
+                }
+                const int incl = wave_incl_scan_add(tot, lane);
+                int ref = carry_ref + incl - tot;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (aln[k]) {
+                        const int ov = min(ref + len[k], e) - max(ref, s);
+                        if (ov > 0) acc += ov;
+                    }
+                    ref += adv[k];
+                }
+                carry_ref += __shfl(incl, 63);
+            }
+            acc = wave_reduce_add64(acc);
+            if (lane == 0 && acc) atomicAdd(&n_bases[j], (unsigned long long)acc);
+        }
+    }
+}
+
+extern "C" int coral_segment_coverage(const coral_records_t *rec, const int32_t *mbases, const int32_t *qinfer,
+                                      int32_t n_seg, const int32_t *seg_tid, const int32_t *seg_start,
+                                      const int32_t *seg_end, unsigned long long *n_reads,
+                                      unsigned long long *n_bases, uint32_t *strad, uint32_t *strad_count,
+                                      void *stream) {
+    int rc = check_records(rec);
+    if (rc) return rc;
+    if (n_seg < 0) return set_err(CORAL_ERR_ARG, "segment_coverage: n_seg < 0");
+    if (n_seg == 0 || rec->n_rec == 0) return CORAL_OK;
+    if (!mbases || !qinfer || !seg_tid || !seg_start || !seg_end || !n_reads || !n_bases || !strad || !strad_count)
+        return set_err(CORAL_ERR_ARG, "segment_coverage: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    long long blocks = (rec->n_rec + COV_BLOCK - 1) / COV_BLOCK;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_seg_classify, dim3((int)blocks), dim3(COV_BLOCK), 0, s, (long long)rec->n_rec, rec->tid,
+                       rec->pos, rec->end, rec->flagmq, rec->n_cigar, mbases, qinfer, (int)n_seg, seg_tid, seg_start,
+                       seg_end, n_reads, n_bases, strad, strad_count);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_err(e, "seg_classify launch");
+    hipLaunchKernelGGL(k_seg_walk, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, s, strad, strad_count, rec->tid,
+                       rec->pos, rec->end, rec->n_cigar, rec->cigar_off, rec->cigar, (int)n_seg, seg_tid, seg_start,
+                       seg_end, n_bases);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_err(e, "seg_walk launch");
+    return CORAL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3  point cover — thread per record, sorted query points
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(COV_BLOCK) void k_point_cover(
+    long long n_rec, const int32_t *__restrict__ tid, const int32_t *__restrict__ pos,
+    const int32_t *__restrict__ end, int n_pts, const int32_t *__restrict__ pt_tid,
+    const int32_t *__restrict__ pt_pos, unsigned long long *__restrict__ pairs,
+    uint32_t *__restrict__ pair_count, uint32_t pair_cap) {
+    const long long stride = (long long)gridDim.x * COV_BLOCK;
+    for (long long r = (long long)blockIdx.x * COV_BLOCK + threadIdx.x; r < n_rec; r += stride) {
+        const int t = tid[r], p = pos[r], e = end[r];
+        if (t < 0) continue;
+        // first point with (pt_tid, pt_pos) >= (t, p)
+        int lo = 0, hi = n_pts;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const int pt = pt_tid[mid];
+            const bool ge = (pt > t) || (pt == t && pt_pos[mid] >= p);
+            if (ge) hi = mid; else lo = mid + 1;
+        }
+        for (int j = lo; j < n_pts && pt_tid[j] == t && pt_pos[j] < e; ++j) {
+            const uint32_t slot = atomicAdd(pair_count, 1u);
+            if (slot < pair_cap) pairs[slot] = ((unsigned long long)(uint32_t)j << 32) | (unsigned long long)(uint32_t)r;
+        }
+    }
+}
+
+extern "C" int coral_point_cover(const coral_records_t *rec, int32_t n_pts, const int32_t *pt_tid,
+                                 const int32_t *pt_pos, unsigned long long *pairs, uint32_t *pair_count,
+                                 uint32_t pair_cap, void *stream) {
+    int rc = check_records(rec);
+    if (rc) return rc;
+    if (n_pts < 0) return set_err(CORAL_ERR_ARG, "point_cover: n_pts < 0");
+    if (n_pts == 0 || rec->n_rec == 0) return CORAL_OK;
+    if (!pt_tid || !pt_pos || !pair_count || (pair_cap && !pairs)) return set_err(CORAL_ERR_ARG, "point_cover: null argument");
+    long long blocks = (rec->n_rec + COV_BLOCK - 1) / COV_BLOCK;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_point_cover, dim3((int)blocks), dim3(COV_BLOCK), 0, (hipStream_t)stream, (long long)rec->n_rec,
+                       rec->tid, rec->pos, rec->end, (int)n_pts, pt_tid, pt_pos, pairs, pair_count, pair_cap);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_err(e, "point_cover launch");
+    return CORAL_OK;
+}
+
+extern "C" int coral_read_counter(const uint32_t *dev_counter, uint32_t *host_value, void *stream) {
+    if (!dev_counter || !host_value) return set_err(CORAL_ERR_ARG, "read_counter: null");
+    hipError_t e = hipMemcpyAsync(host_value, dev_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_err(e, "read_counter copy");
+    e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return hip_err(e, "read_counter sync");
+    return CORAL_OK;
+}

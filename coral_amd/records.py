@@ -1,0 +1,98 @@
+"""Alignment records resident in HBM (structure of arrays) + the small host mirrors the host logic needs.
+
+PyTorch is used for device memory and streams only (plumbing); the kernels are in csrc/ behind the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class DeviceRecords:
+    """Records of one BAM (or one shard of it) in file order.
+
+    Device tensors (HBM):  tid, pos, end, flagmq (flag | mapq<<16 | has_seq<<24), n_cigar : int32[n];
+                           cigar_off : int64[n+1] (multiples of 4); cigar : int32[total] (BAM-packed, op-15 padded)
+    Host mirrors (numpy):  the same per-record fields + qlen, nm, name_id, and the tokenised SA rows.
+    """
+
+    def __init__(self, rec, device="cuda:0"):
+        self.device = torch.device(device)
+        dev = self.device
+        self.n = int(rec.n)
+        self.header_chroms = list(rec.header_chroms)
+        self.header_lens = list(rec.header_lens)
+        i32 = lambda t: t.to(device=dev, dtype=torch.int32).contiguous()
+        self.tid = i32(rec.tid)
+        self.pos = i32(rec.pos)
+        self.end = i32(rec.end)
+        flagmq = (rec.flag.to(torch.int64) & 0xFFFF) | ((rec.mapq.to(torch.int64) & 0xFF) << 16) | \
+                 ((rec.has_seq.to(torch.int64) & 1) << 24)
+        self.flagmq = i32(flagmq)
+        self.n_cigar = i32(rec.n_cigar)
+        self.cigar_off = rec.cigar_off.to(device=dev, dtype=torch.int64).contiguous()
+        self.cigar = rec.cigar.to(device=dev, dtype=torch.int32).contiguous()
+        if self.cigar.numel() == 0:
+            self.cigar = torch.zeros(4, dtype=torch.int32, device=dev)
+        # layout contract of include/coral_hip.h — checked on the host before any kernel can touch the arrays
+        assert self.cigar.data_ptr() % 16 == 0
+        assert self.cigar_off.numel() == self.n + 1
+        if self.n:
+            assert int((self.cigar_off & 3).max()) == 0, "cigar_off must be multiples of 4 ops"
+            assert int(self.cigar_off[-1]) <= self.cigar.numel(), "cigar array shorter than its offsets"
+            span = self.cigar_off[1:] - self.cigar_off[:-1]
+            assert bool((span >= ((self.n_cigar.to(torch.int64) + 3) // 4) * 4).all()), "record ops exceed their slot"
+        # host mirrors
+        h = lambda t: t.detach().cpu().numpy()
+        self.h_tid = h(rec.tid).astype(np.int32)
+        self.h_pos = h(rec.pos).astype(np.int32)
+        self.h_end = h(rec.end).astype(np.int32)
+        self.h_flag = h(rec.flag).astype(np.int32)
+        self.h_mapq = h(rec.mapq).astype(np.int32)
+        self.h_has_seq = h(rec.has_seq).astype(bool)
+        self.h_qlen = np.where(self.h_has_seq, h(rec.qlen), 0).astype(np.int32)    # pysam query_length
+        self.h_nm = h(rec.nm).astype(np.int32)
+        self.h_name_id = h(rec.name_id).astype(np.int32)
+        self.h_n_cigar = h(rec.n_cigar).astype(np.int32)
+        self.h_sa_off = h(rec.sa_off).astype(np.int64)
+        self.h_sa = h(rec.sa).astype(np.int32)
+        self.h_sa_nm = h(rec.sa_nm).astype(np.int32)
+        self.h_nonacgt_rec = h(rec.nonacgt_rec).astype(np.int64)
+        self.h_nonacgt_pos = h(rec.nonacgt_pos).astype(np.int32)
+        self.n_names = int(rec.n_names)
+        self._rec = rec
+        self._names: Optional[List[str]] = rec.names
+        self.total_ops = int(self.h_n_cigar.astype(np.int64).sum())
+        self.n_sa = int(self.h_sa.shape[0])
+        t = np.arange(len(self.header_chroms))
+        self.tid_lo = np.searchsorted(self.h_tid, t, side="left")
+        self.tid_hi = np.searchsorted(self.h_tid, t, side="right")
+
+    @property
+    def names(self) -> List[str]:
+        if self._names is None:
+            self._names = self._rec.materialise_names()
+        return self._names
+
+    def algorithmic_bytes(self) -> int:
+        """SURVEY.md §8(d):  Σ_rec (32 + 4·n_cigar) + 32·N_SA."""
+        return 32 * self.n + 4 * self.total_ops + 32 * self.n_sa
+
+    def c_struct(self) -> _lib.coral_records_t:
+        return _lib.coral_records_t(self.n, self.tid.data_ptr(), self.pos.data_ptr(), self.end.data_ptr(),
+                                    self.flagmq.data_ptr(), self.n_cigar.data_ptr(), self.cigar_off.data_ptr(),
+                                    self.cigar.data_ptr())
+
+    def stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def region(self, tid: int, start: int, stop: int) -> np.ndarray:
+        """Host-side record-level region query (htslib rule pos < stop and end > start), file order."""
+        lo, hi = self.tid_lo[tid], self.tid_hi[tid]
+        m = (self.h_pos[lo:hi] < stop) & (self.h_end[lo:hi] > start)
+        return lo + np.nonzero(m)[0]

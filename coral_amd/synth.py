@@ -717,3 +717,49 @@ def seq_of_record(cfg_seed: int, rec_index: int, length: int) -> np.ndarray:
     k = torch.arange(length, dtype=torch.int64) + rec_index * (1 << 22)
     h = hash_u32(cfg_seed, S_SEQ, k) & 3
     return np.frombuffer(b"ACGT", dtype=np.uint8)[h.numpy()]
+
+
+def records_from_alignments(alns: Sequence[dict], device="cpu") -> Records:
+    """Build a ``Records`` store from hand-written alignments (tests of ragged / odd CIGARs).
+
+    Every alignment is a dict with keys tid, pos, cigar=[(op, len), ...] and optional flag, mapq, name, has_seq,
+    nm, qlen, sa=[(tid, pos1, strand, c5, m, x, c3, mapq, nm), ...], nonacgt=[refpos, ...].  Input must already be
+    in (tid, pos) order.
+    """
+    n = len(alns)
+    ref_ops = {OP_M, OP_D, OP_N, OP_EQ, OP_X}
+    qry_ops = {OP_M, OP_I, OP_S, OP_EQ, OP_X}
+    tid, pos, end, flag, mapq, qlen, has_seq, nm, name_id, n_cig = ([] for _ in range(10))
+    cig, cig_off, sa_rows, sa_nm, sa_off, na_rec, na_pos = [], [0], [], [], [0], [], []
+    names: Dict[str, int] = {}
+    for i, a in enumerate(alns):
+        ops = a.get("cigar", [])
+        unmapped = bool(a.get("flag", 0) & 4)
+        rlen = 0 if unmapped else sum(l for o, l in ops if o in ref_ops)
+        tid.append(a["tid"]); pos.append(a["pos"]); end.append(a["pos"] + max(1, rlen))
+        flag.append(a.get("flag", 0)); mapq.append(a.get("mapq", 60)); has_seq.append(a.get("has_seq", 1))
+        qlen.append(a.get("qlen", sum(l for o, l in ops if o in qry_ops))); nm.append(a.get("nm", 0))
+        nm_ = a.get("name", "r%d" % i)
+        name_id.append(names.setdefault(nm_, len(names)))
+        n_cig.append(len(ops))
+        for o, l in ops:
+            cig.append((l << 4) | o)
+        while len(cig) % 4:
+            cig.append(OP_PAD)
+        cig_off.append(len(cig))
+        for row in a.get("sa", []):
+            sa_rows.append(list(row[:8])); sa_nm.append(row[8])
+        sa_off.append(len(sa_rows))
+        for p in a.get("nonacgt", []):
+            na_rec.append(i); na_pos.append(p)
+    dev = torch.device(device)
+    t32 = lambda x: torch.tensor(x, dtype=torch.int32, device=dev)
+    t64 = lambda x: torch.tensor(x, dtype=torch.int64, device=dev)
+    cg = np.array(cig, dtype=np.uint32).view(np.int32) if cig else np.zeros(0, dtype=np.int32)
+    return Records(n=n, tid=t32(tid), pos=t32(pos), end=t32(end), flag=t32(flag), mapq=t32(mapq), qlen=t32(qlen),
+                   has_seq=t32(has_seq), nm=t32(nm), name_id=t32(name_id), n_cigar=t32(n_cig), cigar_off=t64(cig_off),
+                   cigar=torch.tensor(cg, dtype=torch.int32, device=dev), sa_off=t64(sa_off),
+                   sa=torch.tensor(sa_rows, dtype=torch.int32, device=dev).reshape(-1, 8), sa_nm=t32(sa_nm),
+                   nonacgt_rec=t64(na_rec), nonacgt_pos=t32(na_pos), n_names=len(names),
+                   name_gid=torch.arange(len(names), dtype=torch.int64, device=dev),
+                   names=[k for k, _ in sorted(names.items(), key=lambda kv: kv[1])])

@@ -1,0 +1,125 @@
+/*
+ * coral_hip.h — C ABI of libcoral_hip.so: the MI355X (gfx950) data-parallel hot path of CoRAL's
+ * breakpoint-graph construction.
+ *
+ * The reference (suhas-r/CoRAL @ 2024-10-24) is pure Python and has no FFI of its own; the calls below
+ * replace, one for one, the per-record loops the reference runs through pysam.
+ * Each entry point cites the reference lines it stands in for.  INTEGRATION.md shows the ctypes
+ * binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a plain device (HBM) or host pointer as stated; no framework types;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); launches are asynchronous
+ *     unless a function says it returns a value read back from the device;
+ *   - return value 0 = success, negative = error (see coral_last_error());
+ *   - the library allocates nothing on the device: the caller owns all buffers and workspaces;
+ *   - results are integers and order-free (atomics only ever add integers), so they are bit-exact and
+ *     independent of wave scheduling; compacted lists are returned unordered together with a sort key
+ *     (record ordinal, within-record index) that defines the reference's iteration order.
+ *
+ * Record layout in HBM (structure of arrays, BAM file order = (tid, pos) order):
+ *   tid, pos, end      int32   reference id, 0-based start, htslib bam_endpos
+ *   flagmq             int32   flag | mapq << 16 | has_seq << 24
+ *   n_cigar            int32   number of real CIGAR ops
+ *   cigar_off          int64   offset (in ops) of the record's first op; ALWAYS a multiple of 4
+ *   cigar              uint32  BAM-packed ops (len << 4 | op); every record is padded with op 15 to a
+ *                              multiple of 4 ops so a wave reads whole 16-byte quads
+ */
+#ifndef CORAL_HIP_H
+#define CORAL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CORAL_OK 0
+#define CORAL_ERR_ARG (-1)        /* bad argument (null pointer, unsorted / overlapping segments, ...) */
+#define CORAL_ERR_HIP (-2)        /* a HIP runtime call failed */
+#define CORAL_ERR_CAPACITY (-3)   /* an output list overflowed; *count holds the needed size */
+#define CORAL_ERR_FORMAT (-4)     /* malformed BAM / BGZF input */
+
+typedef struct coral_records {
+    int64_t n_rec;
+    const int32_t *tid;
+    const int32_t *pos;
+    const int32_t *end;
+    const int32_t *flagmq;
+    const int32_t *n_cigar;
+    const int64_t *cigar_off;
+    const uint32_t *cigar;
+} coral_records_t;
+
+const char *coral_version(void);
+const char *coral_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * coral_cigar_scan — ONE fused pass over every CIGAR op in HBM.
+ *
+ * Replaces the per-record `get_blocks()` walk and block loop of find_smalldel_breakpoints
+ * (/root/reference/src/infer_breakpoint_graph.py:750-762), and pre-computes what the later
+ * coverage calls need per record so the CIGAR bytes are streamed once:
+ *   mbases[i]    Σ length of M/=/X ops        (what count_coverage adds for a fully covered record,
+ *                                               infer_breakpoint_graph.py:131, :1033)
+ *   qinfer[i]    Σ length of M/I/S/H/=/X ops  (pysam infer_read_length(), :1031)
+ *   blk_first[i] start of the first aligned block, blk_last[i] end of the last one (-1: none)
+ *                                              (blocks[0][0], blocks[-1][1] at :760)
+ * and appends one row (record, op index of the next block, prev block end, next block start) to
+ * `gaps` for every pair of consecutive blocks further apart than `min_gap` in a record with
+ * mapq >= min_mapq (:754, :757-758).  *gap_count is a device counter the caller zeroes beforehand;
+ * rows beyond gap_cap are dropped (the counter still counts them).
+ * ------------------------------------------------------------------------------------------------ */
+int coral_cigar_scan(const coral_records_t *rec, int32_t min_gap, int32_t min_mapq,
+                     int32_t *mbases, int32_t *qinfer, int32_t *blk_first, int32_t *blk_last,
+                     int32_t *gaps /* [gap_cap][4] */, uint32_t *gap_count, uint32_t gap_cap,
+                     void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * coral_segment_coverage — per-segment record count and aligned-base count.
+ *
+ * Replaces, for S sorted, pairwise disjoint half-open segments (seg_tid, seg_start, seg_end):
+ *   n_reads[j] = #records overlapping the segment with infer_read_length() > 0
+ *                (/root/reference/src/infer_breakpoint_graph.py:1031-1032)
+ *   n_bases[j] = Σ of the four pysam count_coverage arrays with quality_threshold=0,
+ *                read_callback='nofilter' BEFORE the non-ACGT correction (:130-132, :1033-1034):
+ *                aligned (M/=/X) bases of records with SEQ that fall inside the segment.
+ * Records fully inside one segment use mbases[] from coral_cigar_scan; only records straddling a
+ * segment boundary have their CIGAR walked again.  n_reads / n_bases are ADDED to (caller zeroes).
+ * `strad` is a workspace of n_rec uint32 and `strad_count` a zeroed device counter.
+ * ------------------------------------------------------------------------------------------------ */
+int coral_segment_coverage(const coral_records_t *rec, const int32_t *mbases, const int32_t *qinfer,
+                           int32_t n_seg, const int32_t *seg_tid, const int32_t *seg_start,
+                           const int32_t *seg_end, unsigned long long *n_reads,
+                           unsigned long long *n_bases, uint32_t *strad, uint32_t *strad_count,
+                           void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * coral_point_cover — which records cover which query points.
+ *
+ * Replaces the four single-position region fetches per concordant edge
+ * (/root/reference/src/infer_breakpoint_graph.py:1043-1046): for P points sorted by (tid, pos) appends
+ * the packed pair (point index << 32 | record ordinal) for every record with pos <= p < end.
+ * *pair_count is a zeroed device counter; pairs beyond pair_cap are dropped (still counted).
+ * ------------------------------------------------------------------------------------------------ */
+int coral_point_cover(const coral_records_t *rec, int32_t n_pts, const int32_t *pt_tid,
+                      const int32_t *pt_pos, unsigned long long *pairs, uint32_t *pair_count,
+                      uint32_t pair_cap, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * coral_read_counter — copy a device counter to the host (synchronises `stream`).
+ * ------------------------------------------------------------------------------------------------ */
+int coral_read_counter(const uint32_t *dev_counter, uint32_t *host_value, void *stream);
+
+/* Launch-duration probe used by bench.py: runs `fn` = coral_cigar_scan `iters` times between two HIP
+ * events recorded on `stream` (the stream the kernel is launched on) and returns the mean duration of
+ * one launch in milliseconds in *ms_per_launch. */
+int coral_time_cigar_scan(const coral_records_t *rec, int32_t min_gap, int32_t min_mapq,
+                          int32_t *mbases, int32_t *qinfer, int32_t *blk_first, int32_t *blk_last,
+                          int32_t *gaps, uint32_t *gap_count, uint32_t gap_cap, int32_t iters,
+                          float *ms_per_launch, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CORAL_HIP_H */

@@ -1,0 +1,122 @@
+"""GPU parity: every kernel behind the C ABI vs the CPU oracle's per-record primitives (bit-exact integers)."""
+import numpy as np
+import pytest
+import torch
+
+from coral_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _odd_records():
+    M, I, D, N, S, H, P, EQ, X = range(9)
+    alns = [
+        dict(tid=0, pos=100, cigar=[(S, 5), (M, 50), (D, 700), (M, 20), (I, 3), (M, 10)], name="a"),
+        dict(tid=0, pos=120, cigar=[(D, 4), (M, 30), (N, 900), (EQ, 10), (X, 2), (EQ, 5), (H, 7)], name="b"),   # leading D, N gap, =/X
+        dict(tid=0, pos=130, cigar=[], flag=4, name="c", has_seq=1, qlen=40),                                   # placed unmapped, no CIGAR
+        dict(tid=0, pos=140, cigar=[(S, 20), (I, 5)], name="d"),                                              # no aligned block at all
+        dict(tid=0, pos=150, cigar=[(M, 10), (D, 300), (D, 301), (M, 10)], name="e"),                         # adjacent D ops sum to 601
+        dict(tid=0, pos=160, cigar=[(M, 10), (D, 300), (I, 2), (D, 300), (M, 10)], name="f"),                 # 600 exactly: not a gap
+        dict(tid=0, pos=170, cigar=[(M, 10), (D, 800), (M, 10)], mapq=19, name="g"),                          # low MAPQ: no gap rows
+        dict(tid=0, pos=180, cigar=[(M, 200)], has_seq=0, flag=256, name="a"),                                # SEQ-less secondary
+        dict(tid=0, pos=190, cigar=[(M, 5), (P, 2), (M, 5)] + [(I, 1), (M, 3)] * 200, name="h", nonacgt=[191, 193]),  # > 256 ops
+        dict(tid=2, pos=5, cigar=[(M, 1000), (D, 601), (M, 1000), (D, 5000), (M, 10)], name="i"),
+        dict(tid=2, pos=900, cigar=[(M, 4)], name="j"),
+    ]
+    return synth.records_from_alignments(alns)
+
+
+def _cases():
+    yield "odd", _odd_records()
+    for name in ("tiny", "small", "ultra"):
+        yield name, synth.generate(synth.named_config(name), "cpu")
+    yield "cfg1_8k", synth.generate(synth.scaled_config("cfg1", 8000), "cpu")
+
+
+@pytest.fixture(scope="module", params=["odd", "tiny", "small", "ultra", "cfg1_8k"])
+def case(request):
+    from coral_amd.records import DeviceRecords
+    from oracle.hostrecords import HostRecords
+    rec = dict(_cases())[request.param]
+    return request.param, rec, HostRecords(rec), DeviceRecords(rec, "cuda:0")
+
+
+def test_cigar_scan(case):
+    from coral_amd import kernels
+    name, rec, host, dr = case
+    res = kernels.cigar_scan(dr, 600, 20, gap_cap=64)       # small cap: exercises the overflow/retry path
+    mb, qi = res.mbases.cpu().numpy(), res.qinfer.cpu().numpy()
+    b0, b1 = res.blk_first.cpu().numpy(), res.blk_last.cpu().numpy()
+    gaps = []
+    for i in range(host.n):
+        bl = host.blocks(i)
+        assert mb[i] == sum(e - s for s, e in bl), (name, i)
+        assert qi[i] == (host.infer_read_length(i) or 0), (name, i)
+        assert (b0[i], b1[i]) == ((bl[0][0], bl[-1][1]) if bl else (-1, -1)), (name, i)
+        if host.mapq[i] >= 20:
+            for k in range(len(bl) - 1):
+                if abs(bl[k + 1][0] - bl[k][1]) > 600:
+                    gaps.append((i, bl[k][1], bl[k + 1][0]))
+    got = [(int(g[0]), int(g[2]), int(g[3])) for g in res.gaps]
+    assert got == gaps, name
+    if name == "odd":
+        assert len(gaps) == 5     # a, b(N), e, i x2
+
+
+def _random_segments(host, rng, n):
+    segs = []
+    tids = np.unique(host.tid[host.tid >= 0])
+    for _ in range(n):
+        t = int(rng.choice(tids))
+        sel = host.tid == t
+        lo, hi = int(host.pos[sel].min()), int(host.end[sel].max())
+        s = int(rng.integers(lo - 50, hi))
+        e = s + int(rng.choice([1, 2, 17, 300, 5000, 200000]))
+        segs.append((t, s, e))
+    return segs
+
+
+def test_segment_coverage(case):
+    from coral_amd import kernels
+    name, rec, host, dr = case
+    rng = np.random.default_rng(5)
+    res = kernels.cigar_scan(dr)
+    segs = _random_segments(host, rng, 60)
+    # plus a tiling (shared boundaries, as sequence edges have) and an all-covering segment
+    t0 = int(host.tid[0])
+    lo, hi = int(host.pos[host.tid == t0].min()), int(host.end[host.tid == t0].max())
+    cuts = np.unique(np.concatenate([[lo - 10, hi + 10], rng.integers(lo, hi, 12)]))
+    segs += [(t0, int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:])]
+    segs.append((t0, lo - 10, hi + 10))
+    n_reads, n_bases = kernels.segment_coverage(dr, res, segs)
+    for j, (t, s, e) in enumerate(segs):
+        c = host.chroms[t]
+        exp_reads = sum(1 for i in host.region(c, s, e) if host.infer_read_length(i))
+        assert n_reads[j] == exp_reads, (name, j, segs[j])
+        assert n_bases[j] == host.count_coverage_sum(c, s, e), (name, j, segs[j])
+
+
+def test_point_cover(case):
+    from coral_amd import kernels
+    name, rec, host, dr = case
+    rng = np.random.default_rng(6)
+    pts = []
+    for (t, s, e) in _random_segments(host, rng, 40):
+        pts += [(t, s), (t, s + 1), (t, s - 101), (t, s + 101)]
+    pts.append(pts[0])                       # duplicate query point
+    got = kernels.point_cover(dr, pts, pair_cap=128)
+    for (t, p), g in zip(pts, got):
+        exp = host.region(host.chroms[t], p, p + 1)
+        assert np.array_equal(g, exp), (name, t, p)
+
+
+def test_empty_inputs():
+    from coral_amd import kernels
+    from coral_amd.records import DeviceRecords
+    rec = synth.records_from_alignments([])
+    dr = DeviceRecords(rec, "cuda:0")
+    res = kernels.cigar_scan(dr)
+    assert res.gaps.shape[0] == 0 and res.mbases.numel() == 0
+    nr, nb = kernels.segment_coverage(dr, res, [(0, 0, 100)])
+    assert nr.tolist() == [0] and nb.tolist() == [0]
+    assert [g.tolist() for g in kernels.point_cover(dr, [(0, 5)])] == [[]]
