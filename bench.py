@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Headline benchmark: reads/s through the breakpoint-graph build on a synthetic long-read amplicon BAM.
+
+    python bench.py --gpus 1 --steps K --warmup W [--config cfg3] [--reads N]
+
+One "step" = one full pass of the hot path over the resident batch: decoded records already in HBM ->
+BreakpointGraph objects + *_graph.txt written (Gurobi cycle step skipped), i.e. SURVEY.md §8(d)'s timed region.
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: coral_cigar_scan, HIP-event timed on the launch
+stream inside the timed steps) and `cpu_baseline` (the CPU oracle on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--reads", type=int, default=0, help="override the read count of the config (0 = as configured)")
+    ap.add_argument("--cpu-sample", type=int, default=50000, help="reads in the CPU-baseline sample (0 = skip)")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    torch.cuda.set_device(local)
+    dev = "cuda:%d" % local
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    from coral_amd import synth, kernels
+    from coral_amd import infer_breakpoint_graph as ibg
+    from coral_amd.records import DeviceRecords
+    from coral_amd import sharding
+
+    cfg = synth.named_config(a.config)
+    if a.reads:
+        cfg.n_reads = a.reads
+    work = tempfile.mkdtemp(prefix="coral_bench_")
+    cn, seeds = os.path.join(work, "cn.bed"), os.path.join(work, "seeds.bed")
+    synth.write_cn_bed(cfg, cn)
+    synth.write_seed_bed(cfg, seeds)
+
+    t0 = time.time()
+    rec = synth.generate(cfg, dev, chunk_pieces=200000)
+    torch.cuda.synchronize()
+    gen_s = time.time() - t0
+    dr = sharding.shard_records(rec, rank, world, dev)          # world == 1: all records on this GPU
+    n_reads_total = cfg.n_reads
+    alg_bytes_local = dr.algorithmic_bytes()
+    del rec
+    torch.cuda.empty_cache()
+
+    def step(i):
+        prefix = os.path.join(work, "r%d_s%d" % (rank, i))
+        b = sharding.build_graph_sharded(dr, seeds, cn, prefix if rank == 0 else None)
+        return b
+
+    kernels.PROFILE["scan_ms"] = []
+    for i in range(a.warmup):
+        step(-1 - i)
+    kernels.PROFILE["scan_ms"] = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        b = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    scan_ms = [e0.elapsed_time(e1) for e0, e1 in kernels.PROFILE["scan_ms"]]
+    scan_ms_avg = sum(scan_ms) / max(1, len(scan_ms))
+
+    if rank == 0:
+        ms_per_step = dt / a.steps * 1e3
+        value = n_reads_total * a.steps / dt
+        achieved = alg_bytes_local / (scan_ms_avg * 1e-3) / 1e9 if scan_ms_avg > 0 else 0.0
+        out = {
+            "metric": "reads/sec through breakpoint-graph build", "value": value, "unit": "reads/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+            "config": {"workload": "%s: %d reads x %d bp mean, %d seed intervals over %d chroms, full reconstruct incl. CN, "
+                                   "cycle step skipped" % (cfg.name, cfg.n_reads, cfg.mean_len, len(cfg.seeds), len(cfg.windows)),
+                       "records": int(dr.n_total), "cigar_ops": int(dr.total_ops_all), "amplicons": len(b.lr_graph),
+                       "discordant_edges": sum(len(g.discordant_edges) for g in b.lr_graph),
+                       "generate_s": round(gen_s, 2), "parallelism": "records sharded over %d GPU(s)" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_cigar_scan", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None, "launch_ms": scan_ms_avg,
+                         "algorithmic_bytes_per_launch": int(alg_bytes_local)},
+        }
+        if a.cpu_sample and world == 1:
+            out["cpu_baseline"] = cpu_baseline(a.config, min(a.cpu_sample, cfg.n_reads), work)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    shutil.rmtree(work, ignore_errors=True)
+
+
+def cpu_baseline(config, n_sample, work):
+    """The CPU oracle (a port of the reference's per-record Python loops; pysam itself is not installable) on the
+    first ``n_sample`` reads of the same workload, one thread."""
+    import torch
+    from coral_amd import synth
+    from oracle import coral_oracle as O
+    from oracle.hostrecords import HostRecords
+    torch.set_num_threads(1)
+    cfg = synth.scaled_config(config, n_sample)
+    rec = synth.generate(cfg, "cpu")
+    cn, seeds = os.path.join(work, "cpu_cn.bed"), os.path.join(work, "cpu_seeds.bed")
+    synth.write_cn_bed(cfg, cn)
+    synth.write_seed_bed(cfg, seeds)
+    host = HostRecords(rec)
+    t0 = time.perf_counter()
+    O.reconstruct_graph(host, seeds, cn, os.path.join(work, "cpu"))
+    dt = time.perf_counter() - t0
+    return {"value": n_sample / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+            "sample": "first %d reads of %s (same generator and seed), decoded records in host memory -> graph files, %.1f s"
+                      % (n_sample, config, dt)}
+
+
+if __name__ == "__main__":
+    main()

@@ -20,12 +20,6 @@ class coral_records_t(C.Structure):
 
 _lib = None
 
-# every symbol include/coral_hip.h declares (checked by tests/test_cabi.py)
-SYMBOLS = ["coral_version", "coral_last_error", "coral_cigar_scan", "coral_segment_coverage", "coral_point_cover",
-           "coral_read_counter", "coral_time_cigar_scan", "coral_bam_decode_open", "coral_bam_decode_sizes",
-           "coral_bam_decode_fill", "coral_bam_decode_close", "coral_cluster_first_fit"]
-
-
 def lib():
     """Load (once) and return the shared library; raise CoralHipError if it is not built."""
     global _lib
@@ -48,6 +42,8 @@ def lib():
     L.coral_segment_coverage.argtypes = [R, P, P, C.c_int32, P, P, P, P, P, P, P, P]
     L.coral_point_cover.argtypes = [R, C.c_int32, P, P, P, P, C.c_uint32, P]
     L.coral_read_counter.argtypes = [P, C.POINTER(C.c_uint32), P]
+    L.coral_cluster_first_fit.argtypes = [C.c_int64, P, P, C.c_int64, P, C.POINTER(C.c_int32)]
+    L.coral_cluster_first_fit.restype = C.c_int
     for name in ("coral_cigar_scan", "coral_time_cigar_scan", "coral_segment_coverage", "coral_point_cover",
                  "coral_read_counter"):
         getattr(L, name).restype = C.c_int

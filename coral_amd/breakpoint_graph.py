@@ -1,0 +1,244 @@
+"""BreakpointGraph container, long-read CN assignment and the ``*_graph.txt`` / ``*_breakpoints.txt`` writers.
+
+Mirrors the surface of the reference's ``breakpoint_graph.py`` that the graph-build path uses
+(/root/reference/src/breakpoint_graph.py:83-207 container, :348-363 sort_edges, :495-606 compute_cn_lr,
+:805-822 and :845-854 writers) so that downstream consumers (cycle decomposition, path constraints, plot)
+see the same fields:
+
+    sequence_edges[i]   = [chr, l, r, sr_count, sr_flag, lr_count, lr_nc, size, cn]
+    concordant_edges[i] = [c1, p1, o1, c2, p2, o2, sr_count, sr_flag, lr_count, reads:set[str], cn]
+    discordant_edges[i] = [c1, p1, o1, c2, p2, o2, sr_count, sr_flag, sr_cn, lr_count, reads:set[(name,i,j)], cn]
+    nodes               = {(chr, pos, o): [[seq], [conc], [disc], [src]]}   (insertion ordered)
+
+The CN step does not use cvxopt: ``solve_cn_lr`` minimises the reference's objective (bg:546-556) under
+the same balance constraints (bg:531-543) by Newton's method on the KKT system to machine precision.
+The edge-list functions below work on ANY object with these attributes, so a maintainer can keep the
+reference's own BreakpointGraph class (with its cycle-step helpers) as the container: see INTEGRATION.md.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .global_names import chr_idx
+
+
+class BreakpointGraph:
+    def __init__(self):
+        self.amplicon_intervals = []
+        self.sequence_edges = []
+        self.concordant_edges = []
+        self.discordant_edges = []
+        self.source_edges = []
+        self.nodes = dict()
+        self.endnodes = dict()
+        self.max_cn = 0.0
+
+    # -- nodes ---------------------------------------------------------------------------------
+    def add_node(self, node_):
+        if type(node_) != tuple or len(node_) != 3:
+            raise Exception("Breakpoint node must be of form (chr, pos, orientation).")
+        self.nodes[node_] = [[], [], [], []]          # re-adding resets the adjacency, as bg:122-124 does
+
+    def add_endnode(self, node_):
+        if type(node_) != tuple or len(node_) != 3:
+            raise Exception("Breakpoint node must be of form (chr, pos, orientation).")
+        if node_ not in self.endnodes:
+            self.endnodes[node_] = []
+
+    # -- edges ---------------------------------------------------------------------------------
+    def add_sequence_edge(self, chr, l, r, sr_count=-1, sr_flag='d', lr_count=-1, lr_nc=0, cn=0.0):
+        if (chr, l, '-') not in self.nodes or (chr, r, '+') not in self.nodes:
+            raise Exception("Breakpoint node must be added first.")
+        k = len(self.sequence_edges)
+        self.nodes[(chr, l, '-')][0].append(k)
+        self.nodes[(chr, r, '+')][0].append(k)
+        self.sequence_edges.append([chr, l, r, sr_count, sr_flag, lr_count, lr_nc, r - l + 1, cn])
+
+    def add_concordant_edge(self, chr1, pos1, o1, chr2, pos2, o2, sr_count=-1, sr_flag='d', lr_count=-1,
+                            reads=None, cn=0.0):
+        if chr1 != chr2 or pos2 != pos1 + 1 or o1 != '+' or o2 != '-':
+            raise Exception("Invalid concordant edge.")
+        if (chr1, pos1, o1) not in self.nodes or (chr2, pos2, o2) not in self.nodes:
+            raise Exception("Breakpoint node must be added first.")
+        k = len(self.concordant_edges)
+        self.nodes[(chr1, pos1, o1)][1].append(k)
+        self.nodes[(chr2, pos2, o2)][1].append(k)
+        self.concordant_edges.append([chr1, pos1, o1, chr2, pos2, o2, sr_count, sr_flag, lr_count,
+                                      set() if reads is None else reads, cn])
+
+    def add_discordant_edge(self, chr1, pos1, o1, chr2, pos2, o2, sr_count=-1, sr_flag='d', sr_cn=0.0, lr_count=-1,
+                            reads=None, cn=0.0):
+        if (chr1, pos1, o1) not in self.nodes or (chr2, pos2, o2) not in self.nodes:
+            raise Exception("Breakpoint node must be added first.")
+        k = len(self.discordant_edges)
+        self.nodes[(chr1, pos1, o1)][2].append(k)
+        self.nodes[(chr2, pos2, o2)][2].append(k)
+        for nd in ((chr1, pos1, o1), (chr2, pos2, o2)):
+            if nd in self.endnodes:
+                self.endnodes[nd].append(k)
+        self.discordant_edges.append([chr1, pos1, o1, chr2, pos2, o2, sr_count, sr_flag, sr_cn, lr_count,
+                                      set() if reads is None else reads, cn])
+
+    def add_source_edge(self, chr1, pos1, o1, sr_count=0, sr_flag='d', sr_cn=0.0, lr_cn=0.0, cn=0.0):
+        if (chr1, pos1, o1) not in self.nodes:
+            raise Exception("Breakpoint node must be added first.")
+        self.nodes[(chr1, pos1, o1)][3].append(len(self.source_edges))
+        self.source_edges.append(['source', -1, '-', chr1, pos1, o1, sr_count, sr_flag, sr_cn, lr_cn, cn])
+
+    def sort_edges(self):
+        self.sequence_edges.sort(key=lambda e: (chr_idx[e[0]], e[1]))
+        self.concordant_edges.sort(key=lambda e: (chr_idx[e[0]], e[1]))
+        for k, e in enumerate(self.sequence_edges):
+            self.nodes[(e[0], e[1], '-')][0] = [k]
+            self.nodes[(e[0], e[2], '+')][0] = [k]
+        for k, e in enumerate(self.concordant_edges):
+            self.nodes[(e[0], e[1], e[2])][1] = [k]
+            self.nodes[(e[3], e[4], e[5])][1] = [k]
+
+    def compute_cn_lr(self, normal_cov_lr):
+        compute_cn_lr(self, normal_cov_lr)
+
+
+# ----------------------------------------------------------------------------------------------
+# CN assignment (replaces cvxopt.solvers.cp at bg:558-563)
+# ----------------------------------------------------------------------------------------------
+def cn_problem(g, normal_cov):
+    """Weights (bg:514-525) and the dense balance matrix (bg:531-543; variable order seq, conc, disc, src;
+    one row per non-end node in ``nodes`` insertion order; entries are assigned, not accumulated)."""
+    ls, lc, ld, lsrc = len(g.sequence_edges), len(g.concordant_edges), len(g.discordant_edges), len(g.source_edges)
+    n = ls + lc + ld + lsrc
+    w_lin = np.empty(n)
+    w_log = np.empty(n)
+    w_inv = np.zeros(n)
+    for k, e in enumerate(g.sequence_edges):
+        w_lin[k] = 0.5 * normal_cov * e[7]
+        w_log[k] = -0.5
+        w_inv[k] = 0.5 * e[6] ** 2 / (normal_cov * e[7])
+    for k, e in enumerate(g.concordant_edges):
+        w_lin[ls + k] = normal_cov
+        w_log[ls + k] = e[8] * 1.0
+    for k, e in enumerate(g.discordant_edges):
+        w_lin[ls + lc + k] = normal_cov
+        w_log[ls + lc + k] = e[9] * 1.0
+    for k, e in enumerate(g.source_edges):
+        w_lin[ls + lc + ld + k] = 0.5 * normal_cov
+        w_log[ls + lc + ld + k] = -0.5
+        w_inv[ls + lc + ld + k] = 0.5 * e[-1] ** 2 / normal_cov
+    interior = [nd for nd in g.nodes if nd not in g.endnodes]
+    A = np.zeros((len(interior), n))
+    for row, nd in enumerate(interior):
+        adj = g.nodes[nd]
+        A[row, adj[0]] = 1
+        A[row, [ls + k for k in adj[1]]] = -1
+        A[row, [ls + lc + k for k in adj[2]]] = -1
+        A[row, [ls + lc + ld + k for k in adj[3]]] = -1
+    return w_inv, w_lin, w_log, A
+
+
+def solve_cn_lr(w_inv, w_lin, w_log, A, tol=1e-13, max_iter=500):
+    """argmin  Σ w_inv/x + w_lin·x − w_log·log x   s.t.  A x = 0,  x > 0,   started at x = 1 (bg:546-548).
+
+    Infeasible-start Newton on the full KKT system [[H, Aᵀ], [A, 0]] (H diagonal, possibly with zero
+    entries for concordant edges without read support; A possibly rank deficient -> least squares), with
+    a backtracking search on the KKT residual that keeps x strictly positive.  float64 throughout.
+    """
+    n, p = len(w_lin), A.shape[0]
+    x = np.ones(n)
+    nu = np.zeros(p)
+    scale = max(1.0, float(np.max(np.abs(w_lin)))) if n else 1.0
+    K = np.zeros((n + p, n + p))
+    K[:n, n:] = A.T
+    K[n:, :n] = A
+    diag = np.arange(n)
+
+    def kkt_residual(x, nu):
+        return np.concatenate([w_lin - w_log / x - w_inv / (x * x) + A.T @ nu, A @ x])
+
+    r = kkt_residual(x, nu)
+    for _ in range(max_iter):
+        K[diag, diag] = w_log / (x * x) + 2.0 * w_inv / (x * x * x)
+        step = np.linalg.lstsq(K, -r, rcond=None)[0]
+        dx, dnu = step[:n], step[n:]
+        t = 1.0
+        shrink = dx < 0
+        if shrink.any():
+            t = min(1.0, 0.99 * float(np.min(-x[shrink] / dx[shrink])))
+        r0 = np.linalg.norm(r)
+        while t > 1e-14:
+            r_new = kkt_residual(x + t * dx, nu + t * dnu)
+            if np.linalg.norm(r_new) <= (1.0 - 0.01 * t) * r0:
+                break
+            t *= 0.5
+        else:
+            r_new = kkt_residual(x + t * dx, nu + t * dnu)
+        x = x + t * dx
+        nu = nu + t * dnu
+        r = r_new
+        if np.max(np.abs(r[:n])) <= tol * scale and (p == 0 or np.max(np.abs(r[n:])) <= tol * max(1.0, float(np.max(x)))) \
+                and np.max(np.abs(t * dx) / x) < 1e-13:
+            break
+    return x
+
+
+def compute_cn_lr(g, normal_cov_lr):
+    """Fill the CN field of every edge of ``g`` and ``g.max_cn`` (bg:495-606)."""
+    ls, lc, ld = len(g.sequence_edges), len(g.concordant_edges), len(g.discordant_edges)
+    w_inv, w_lin, w_log, A = cn_problem(g, normal_cov_lr)
+    if A.shape[0] > 0:
+        x = solve_cn_lr(w_inv, w_lin, w_log, A)
+        doubled = [float(v) * 2 for v in x]
+        for k in range(ls):
+            g.sequence_edges[k][-1] = doubled[k]
+        for k in range(lc):
+            g.concordant_edges[k][-1] = doubled[ls + k]
+        for k in range(ld):
+            e = g.discordant_edges[k]
+            self_loop = e[0] == e[3] and e[1] == e[4] and e[2] == e[5]
+            e[-1] = float(x[ls + lc + k]) if self_loop else doubled[ls + lc + k]      # bg:585-592
+        for k in range(len(g.source_edges)):
+            g.source_edges[k][-1] = doubled[ls + lc + ld + k]
+        for lst in (g.sequence_edges, g.concordant_edges, g.discordant_edges, g.source_edges):
+            for e in lst:
+                if e[-1] > g.max_cn:
+                    g.max_cn = e[-1]
+    else:
+        assert lc == 0 and ld == 0 and len(g.source_edges) == 0
+        for e in g.sequence_edges:
+            e[-1] = e[6] * 2.0 / (normal_cov_lr * e[7])
+            if e[-1] > g.max_cn:
+                g.max_cn = e[-1]
+    g.max_cn += 1.0
+
+
+# ----------------------------------------------------------------------------------------------
+# writers
+# ----------------------------------------------------------------------------------------------
+def graph_text(g) -> str:
+    rows = ["SequenceEdge: StartPosition, EndPosition, PredictedCN, AverageCoverage, Size, NumberOfLongReads\n"]
+    for e in g.sequence_edges:
+        rows.append("sequence\t%s:%s-\t%s:%s+\t%f\t%f\t%d\t%d\n" % (e[0], e[1], e[0], e[2], e[-1], e[6] * 1.0 / e[7], e[7], e[5]))
+    rows.append("BreakpointEdge: StartPosition->EndPosition, PredictedCN, NumberOfLongReads\n")
+    for e in g.source_edges:
+        rows.append("source\t%s:%s%s->%s:%s%s\t%f\t-1\n" % (e[0], e[1], e[2], e[3], e[4], e[5], e[-1]))
+    for e in g.concordant_edges:
+        rows.append("concordant\t%s:%s%s->%s:%s%s\t%f\t%d\n" % (e[0], e[1], e[2], e[3], e[4], e[5], e[-1], e[8]))
+    for e in g.discordant_edges:
+        rows.append("discordant\t%s:%s%s->%s:%s%s\t%f\t%d\n" % (e[0], e[1], e[2], e[3], e[4], e[5], e[-1], e[9]))
+    return "".join(rows)
+
+
+def output_breakpoint_graph_lr(g, ogfile):
+    with open(ogfile, 'w') as fp:
+        fp.write(graph_text(g))
+
+
+def breakpoint_info_text(g, bp_stats) -> str:
+    rows = ["chr1\tpos1\tchr2\tpos2\torientation\tlr_support\tlr_info=[avg1, avg2, std1, std2, mapq1, mapq2]\n"]
+    for k, e in enumerate(g.discordant_edges):
+        rows.append("%s\t%s\t%s\t%s\t%s%s\t%d\t%s\n" % (e[3], e[4], e[0], e[1], e[5], e[2], e[9], bp_stats[k]))
+    return "".join(rows)
+
+
+def output_breakpoint_info_lr(g, obpfile, bp_stats):
+    with open(obpfile, 'w') as fp:
+        fp.write(breakpoint_info_text(g, bp_stats))

@@ -1,0 +1,1044 @@
+"""MI355X-native breakpoint-graph construction behind the reference's operator interface.
+
+Drop-in for ``infer_breakpoint_graph.reconstruct_graph(args)``
+(/root/reference/src/infer_breakpoint_graph.py:1333-1395): same arguments, same side effects (log file,
+``{prefix}_amplicon{N}_graph.txt`` / ``_breakpoints.txt``), same attribute surface on the returned
+``bam_to_breakpoint_nanopore`` object.
+
+What runs where
+  * BAM is decoded ONCE into structure-of-arrays records resident in HBM (coral_amd.records / coral_amd.bam);
+  * every per-record loop of the reference is a HIP kernel behind the C ABI (include/coral_hip.h):
+      coral_cigar_scan        <- get_blocks() walk of find_smalldel_breakpoints (ibg:750-762) + per-record sums
+      coral_segment_coverage  <- count_coverage / fetch counting of read_cns (ibg:130-133) and assign_cov (ibg:1031-1034)
+      coral_point_cover       <- the four point fetches per concordant edge (ibg:1043-1046)
+  * the per-read SA parsing and read->candidate steps are vectorised over all SA rows (coral_amd.chimeric);
+  * the small, order-sensitive steps (interval BFS, first-fit clustering, graph assembly) stay on the host with
+    the reference's container types, because the reference's own output order depends on them (set-of-str
+    iteration, dict insertion order — SURVEY.md Appendix A Q21).
+
+There is no CPU fallback: importing works without a GPU, running needs libcoral_hip.so and an MI355X.
+"""
+from __future__ import annotations
+
+import logging
+import math
+import sys
+import time
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import global_names, kernels
+from .bpcluster import bpc2bp, cluster_bp_list
+from .breakpoint_graph import (BreakpointGraph, breakpoint_info_text, compute_cn_lr, graph_text,
+                               output_breakpoint_graph_lr, output_breakpoint_info_lr)
+from .chimeric import (Candidates, ChimericTable, build_chimeric_table, candidates_between, candidates_within)
+from .global_names import chr_idx
+
+_ORI = "+-"
+
+
+def _t():
+    return "#TIME " + '%.4f\t' % (time.time() - global_names.TSTART)
+
+
+def interval_overlap(a, b):
+    return a[0] == b[0] and int(a[1]) <= int(b[2]) and int(b[1]) <= int(a[2])
+
+
+def interval_adjacent(a, b):
+    if a[0] != b[0]:
+        return False
+    return (b[1] == a[2] + 1) if a[1] <= b[1] else (a[1] == b[2] + 1)
+
+
+def interval_overlap_l(a, lst):
+    for k, b in enumerate(lst):
+        if interval_overlap(a, b):
+            return k
+    return -1
+
+
+def interval_exclusive(a, lst):
+    """Parts of ``a`` not covered by the intervals of ``lst`` and the indices it overlaps (bu:54-67)."""
+    hit = set()
+    parts = [list(a)]
+    for k, b in enumerate(lst):
+        for j in range(len(parts) - 1, -1, -1):
+            p = parts[j]
+            if interval_overlap(p, b):
+                hit.add(k)
+                del parts[j]
+                if p[1] < b[1]:
+                    parts.append([p[0], p[1], b[1] - 1, -1])
+                if p[2] > b[2]:
+                    parts.append([p[0], b[2] + 1, p[2], -1])
+    return hit, parts
+
+
+class _ChimericAlignments(dict):
+    """``name -> (qint, rint(+cniset), qual, nm)`` exactly as the reference stores it, materialised from the
+    ChimericTable the first time an entry is read (keys exist from the start, in the reference's order)."""
+
+    def __init__(self, owner, names_in_order):
+        super().__init__(dict.fromkeys(names_in_order))
+        self._owner = owner
+        self._index = {nm: k for k, nm in enumerate(names_in_order)}
+
+    def _make(self, key):
+        o = self._owner
+        T = o._chim
+        r = self._index[key]
+        if T.failed[r]:
+            return ([], [], [])
+        a, b = int(T.off[r]), int(T.off[r + 1])
+        chroms = o.rec.header_chroms
+        qint = [[int(T.qs[k]), int(T.qe[k])] for k in range(a, b)]
+        rint = []
+        for k in range(a, b):
+            seg = [chroms[T.tid[k]], int(T.ra[k]), int(T.rb[k]), _ORI[T.strand[k]]]
+            if o._hashed:
+                seg.append(o._cniset(k))
+            rint.append(seg)
+        qual = [int(T.mapq[k]) for k in range(a, b)]
+        nm = [float(T.nm[k]) for k in range(a, b)]
+        return (qint, rint, qual, nm)
+
+    def __getitem__(self, key):
+        v = dict.__getitem__(self, key)
+        if v is None:
+            v = self._make(key)
+            dict.__setitem__(self, key, v)
+        return v
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in dict.keys(self)]
+
+    def values(self):
+        return [self[k] for k in dict.keys(self)]
+
+    def __delitem__(self, key):
+        dict.__delitem__(self, key)
+
+    def invalidate(self):
+        for k in dict.keys(self):
+            dict.__setitem__(self, k, None)
+
+
+class _RecordsFile:
+    """Stand-in for ``lr_bamfh`` after decoding: region fetch + close, as compute_path_constraints uses them
+    (ibg:1306-1310)."""
+
+    class _Rec:
+        __slots__ = ("query_name", "mapq", "mapping_quality", "reference_name", "reference_start", "reference_end", "flag")
+
+    def __init__(self, dr):
+        self._dr = dr
+
+    def fetch(self, contig=None, start=None, stop=None, **kw):
+        dr = self._dr
+        if contig is None:
+            idx = np.nonzero(dr.h_tid >= 0)[0]
+        else:
+            tid = dr.header_chroms.index(contig)
+            idx = dr.region(tid, 0 if start is None else start, (1 << 40) if stop is None else stop)
+        names = dr.names
+        for i in idx:
+            r = self._Rec()
+            r.query_name = names[dr.h_name_id[i]]
+            r.mapq = r.mapping_quality = int(dr.h_mapq[i])
+            r.reference_name = dr.header_chroms[dr.h_tid[i]]
+            r.reference_start = int(dr.h_pos[i])
+            r.reference_end = int(dr.h_end[i])
+            r.flag = int(dr.h_flag[i])
+            yield r
+
+    def close(self):
+        pass
+
+
+class bam_to_breakpoint_nanopore():
+    max_seq_len = 2000000
+    cn_gain = 5.0
+    min_bp_match_cutoff_ = 100
+    interval_delta = 100000
+    max_breakpoint_distance_cutoff = 2000
+    min_del_len = 600
+
+    def __init__(self, lr_bamfile, seedfile, records=None, device="cuda:0"):
+        if records is None:
+            from .bam import decode_bam
+            from .records import DeviceRecords
+            records = DeviceRecords(decode_bam(lr_bamfile), device)
+        self.rec = records
+        self.lr_bamfh = _RecordsFile(records)
+        self.lr_graph = []
+        self.min_bp_cov_factor = 1.0
+        self.min_cluster_cutoff = 3
+        self.read_length = dict()
+        self.chimeric_alignments = dict()
+        self.chimeric_alignments_seg = dict()
+        self.large_indel_alignments = dict()
+        self.nm_stats = [0.0, 0.0, 0]
+        self.nm_filter = False
+        self.amplicon_intervals = []
+        self.amplicon_interval_connections = dict()
+        self.cns_intervals = []
+        self.cns_intervals_by_chr = dict()
+        self.log2_cn = []
+        self.cns_tree = dict()
+        self.normal_cov = 0.0
+        self.ccid2id = dict()
+        self.new_bp_list = []
+        self.new_bp_stats = []
+        self.new_bp_ccids = []
+        self.source_edges = []
+        self.source_edge_ccids = []
+        self.path_constraints = dict()
+        self.longest_path_constraints = dict()
+        self.cycles = dict()
+        self.cycle_weights = dict()
+        self.path_constraints_satisfied = dict()
+        self._scan = None
+        self._chim: Optional[ChimericTable] = None
+        self._hashed = False
+        chroms = self.rec.header_chroms
+        self._tid_of = {c: k for k, c in enumerate(chroms)}
+        self._chr_rank = np.array([chr_idx.get(c, -1) for c in chroms], dtype=np.int64)
+        with open(seedfile, 'r') as fp:
+            for line in fp:
+                s = line.strip().split()
+                self.amplicon_intervals.append([s[0], int(s[1]), int(s[2]), -1])
+        logging.debug(_t() + "Parsed %d seed amplicon intervals." % (len(self.amplicon_intervals)))
+
+    # ------------------------------------------------------------------------------------------
+    def scan(self):
+        """The fused CIGAR pass (coral_cigar_scan); run once, reused by every later step."""
+        if self._scan is None:
+            self._scan = kernels.cigar_scan(self.rec, self.min_del_len, 20)
+        return self._scan
+
+    def _coverage(self, segs):
+        """[(chr, start, end_inclusive)] -> (n_reads, n_bases) via coral_segment_coverage."""
+        tri = [(self._tid_of[c], int(s), int(e) + 1) for c, s, e in segs]
+        return kernels.segment_coverage(self.rec, self.scan(), tri)
+
+    # ---- A1 / A2 -----------------------------------------------------------------------------
+    def read_cns(self, cns):
+        """Parse the CN segments and estimate the normal long-read coverage (ibg:75-136)."""
+        self.cns_intervals, self.log2_cn = [], []
+        tree: Dict[str, list] = {}
+        idx = 0
+        with open(cns, 'r') as fp:
+            for line in fp:
+                s = line.strip().split()
+                if s[0] == "chromosome":
+                    continue
+                self.cns_intervals.append([s[0], int(s[1]), int(s[2]) - 1])
+                if s[0] not in tree:
+                    tree[s[0]] = []
+                    self.cns_intervals_by_chr[s[0]] = []
+                    idx = 0
+                tree[s[0]].append((int(s[1]), int(s[2]), idx))
+                idx += 1
+                if cns.endswith(".cns"):
+                    self.cns_intervals_by_chr[s[0]].append([s[0], int(s[1]), int(s[2]) - 1, 2 * (2 ** float(s[4]))])
+                    self.log2_cn.append(float(s[4]))
+                elif cns.endswith(".bed"):
+                    self.cns_intervals_by_chr[s[0]].append([s[0], int(s[1]), int(s[2]) - 1, float(s[3])])
+                    self.log2_cn.append(np.log2(float(s[3]) / 2.0))
+                else:
+                    sys.stderr.write(cns + "\n")
+                    sys.stderr.write("Invalid cn_seg file format!\n")
+        self.cns_tree = {}
+        for c, v in tree.items():
+            st, en, ix = (np.array(col, dtype=np.int64) for col in zip(*v))
+            o = np.argsort(st, kind="stable")
+            disjoint = bool((en[o][:-1] <= st[o][1:]).all())
+            self.cns_tree[c] = (st, en, ix, o, disjoint)
+        logging.debug(_t() + "Total num LR copy number segments: %d." % (len(self.log2_cn)))
+        order = np.argsort(self.log2_cn)
+        im = int(len(order) / 2.4)
+        ip = im + 1
+        picked = [self.cns_intervals[order[ip]], self.cns_intervals[order[im]]]
+        total_int_len = sum(p[2] - p[1] + 1 for p in picked)
+        i = 1
+        while total_int_len < 10000000:
+            for p in (self.cns_intervals[order[ip + i]], self.cns_intervals[order[im - i]]):
+                picked.append(p)
+                total_int_len += p[2] - p[1] + 1
+            i += 1
+        logging.debug(_t() + "Use %d LR copy number segments." % (len(picked)))
+        logging.debug(_t() + "Total length of LR copy number segments: %d." % (total_int_len))
+        _, n_bases = self._coverage(picked)
+        nnc = int(n_bases.sum())
+        self.normal_cov = nnc * 1.0 / total_int_len
+        logging.info(_t() + "LR normal cov = %f." % (self.normal_cov))
+        self.min_cluster_cutoff = max(self.min_cluster_cutoff, self.min_bp_cov_factor * self.normal_cov)
+        logging.debug(_t() + "Reset min_cluster_cutoff to %f." % (self.min_cluster_cutoff))
+
+    def pos2cni(self, chr, pos):
+        """Indices of the CN segments containing ``pos`` (the reference's IntervalTree point query, ibg:177-178)."""
+        st, en, ix, _, _ = self.cns_tree[chr]
+        return ix[(st <= pos) & (pos < en)].tolist()
+
+    def _pos2cni_many(self, chr, pos: np.ndarray) -> np.ndarray:
+        """Vectorised point query: CN-segment index or -1; asserts at most one hit like ibg:191."""
+        st, en, ix, o, disjoint = self.cns_tree[chr]
+        if disjoint:
+            k = np.searchsorted(st[o], pos, side="right") - 1
+            kk = np.clip(k, 0, len(o) - 1)
+            ok = (k >= 0) & (pos < en[o][kk])
+            return np.where(ok, ix[o][kk], -1)
+        hits = (st[None, :] <= pos[:, None]) & (pos[:, None] < en[None, :])
+        assert (hits.sum(1) <= 1).all()
+        return np.where(hits.any(1), ix[np.argmax(hits, 1)], -1)
+
+    # ---- A3 ----------------------------------------------------------------------------------
+    def fetch(self):
+        """Collect chimeric alignments of every read from the SA tags (ibg:139-174)."""
+        T = build_chimeric_table(self.rec)
+        self._chim = T
+        if T.n_mapq60_plain == 0:
+            raise ZeroDivisionError("float division by zero")                # ibg:159
+        e = T.nm_e
+        s0 = float(np.cumsum(e)[-1])                                          # sequential adds, as the reference
+        s1 = float(np.cumsum(e * e)[-1])
+        mean = s0 / T.n_mapq60_plain
+        self.nm_stats = [mean, math.sqrt(s1 / T.n_mapq60_plain - mean ** 2), T.n_mapq60_plain]
+        names = self.rec.names
+        has = np.nonzero(T.read_length >= 0)[0]
+        self.read_length = _LazyReadLength(names, T.read_length, has)
+        self._chim_names = [names[i] for i in T.name_id]
+        self.chimeric_alignments = _ChimericAlignments(self, self._chim_names)
+        self._chim_index = self.chimeric_alignments._index
+        logging.info(_t() + "Fetched %d chimeric reads." % (len(self.chimeric_alignments)))
+        logging.info(_t() + "Computed alignment intervals on all chimeric reads.")
+
+    # ---- A4 ----------------------------------------------------------------------------------
+    def _cniset(self, row):
+        T = self._chim
+        if T.cni0[row] == -3:
+            return set([-1])
+        s = set([int(T.cni0[row]), int(T.cni1[row])])
+        if len(s) > 1 and -1 in s:
+            s.remove(-1)
+        return s
+
+    def hash_alignment_to_seg(self):
+        """CN-segment indices of both ends of every SA segment + the inverted index (ibg:181-210)."""
+        T = self._chim
+        chroms = self.rec.header_chroms
+        lo = np.minimum(T.ra, T.rb)
+        hi = np.maximum(T.ra, T.rb)
+        T.cni0[:] = -3                     # -3: chromosome absent from the CN file -> set([-1]) (ibg:210)
+        T.cni1[:] = -3
+        for t in np.unique(T.tid):
+            c = chroms[t]
+            if c not in self.cns_tree:
+                continue
+            m = T.tid == t
+            T.cni0[m] = self._pos2cni_many(c, lo[m])
+            T.cni1[m] = self._pos2cni_many(c, hi[m])
+        self._hashed = True
+        self.chimeric_alignments.invalidate()
+        # inverted index (chr, cni) -> reads, in the reference's append order (read, then segment)
+        known = T.cni0 != -3
+        rows = np.nonzero(known)[0]
+        a, b = T.cni0[rows], T.cni1[rows]
+        e_row = np.concatenate([rows[a >= 0], rows[(b >= 0) & (b != a)]])
+        e_cni = np.concatenate([a[a >= 0], b[(b >= 0) & (b != a)]])
+        o = np.lexsort((e_row, e_cni, T.tid[e_row]))
+        self._e_row, self._e_cni = e_row[o], e_cni[o]
+        self._e_tid = T.tid[self._e_row]
+        self._e_key = self._e_tid * (1 << 32) + self._e_cni
+        kt = T.tid[rows]
+        ut, ft = np.unique(kt, return_index=True)
+        self._seg_tids = [int(t) for t in ut[np.argsort(ft, kind="stable")]]     # dict key order of ibg:201-202
+        self.chimeric_alignments_seg = _SegIndexView(self)
+
+    # ---- A5 ----------------------------------------------------------------------------------
+    def find_amplicon_intervals(self):
+        by = self.cns_intervals_by_chr
+        logging.debug(_t() + "Updating seed amplicon intervals according to CN segments.")
+        for iv in self.amplicon_intervals:
+            c = iv[0]
+            lcni = self.pos2cni(c, iv[1])[0]
+            rcni = self.pos2cni(c, iv[2])[0]
+            iv[1] = by[c][lcni][1]
+            if self.pos2cni(c, by[c][lcni][1] - self.interval_delta):
+                iv[1] = by[c][lcni][1] - self.interval_delta
+            iv[2] = by[c][rcni][2]
+            if self.pos2cni(c, by[c][rcni][2] + self.interval_delta):
+                iv[2] = by[c][rcni][2] + self.interval_delta
+        ccid = 0
+        for ai in range(len(self.amplicon_intervals)):
+            if self.amplicon_intervals[ai][3] == -1:
+                self.find_interval_i(ai, ccid)
+                ccid += 1
+        logging.debug(_t() + "Identified %d amplicon intervals in total." % len(self.amplicon_intervals))
+        self._merge_intervals()
+
+    def _merge_intervals(self):
+        """Sort, merge adjacent / overlapping intervals, remap connections, relabel components (ibg:236-319)."""
+        ivs = self.amplicon_intervals
+        order = sorted(range(len(ivs)), key=lambda i: (chr_idx[ivs[i][0]], ivs[i][1]))
+        srt = [ivs[i] for i in order]
+        runs, first = [], 0
+        for k in range(len(srt) - 1):
+            if not (interval_adjacent(srt[k + 1], srt[k]) or interval_overlap(srt[k], srt[k + 1])):
+                if k > first:
+                    runs.append((first, k))
+                first = k + 1
+        if srt and first < len(srt) - 1:
+            runs.append((first, len(srt) - 1))
+        conn = self.amplicon_interval_connections
+        for a, b in reversed(runs):
+            srt[a][2] = srt[b][2]
+            for k in range(a + 1, b + 1):
+                if srt[k][3] != srt[a][3]:
+                    old = srt[k][3]
+                    for iv in srt:
+                        if iv[3] == old:
+                            iv[3] = srt[a][3]
+            cmap = {key: key for key in conn}
+            for k in range(a + 1, b + 1):
+                keep, gone = order[a], order[k]
+                for key in cmap:
+                    u, v = cmap[key]
+                    if gone == u:
+                        u = keep
+                    cmap[key] = (u, v)
+                    if gone == cmap[key][1]:
+                        cmap[key] = (cmap[key][0], keep)
+                    if cmap[key][1] < cmap[key][0]:
+                        cmap[key] = (cmap[key][1], cmap[key][0])
+            for key, new in cmap.items():
+                if key != new:
+                    if new not in conn:
+                        conn[new] = conn[key]
+                    else:
+                        conn[new] |= conn[key]
+                    del conn[key]
+                    if new[0] == new[1]:
+                        del conn[new]
+            for k in range(b, a, -1):
+                del srt[k]
+                del order[k]
+        self.amplicon_intervals = list(srt)
+        where = {order[i]: i for i in range(len(order))}
+        renamed = {key: (min(where[key[0]], where[key[1]]), max(where[key[0]], where[key[1]])) for key in conn}
+        self.amplicon_interval_connections = {renamed[key]: conn[key] for key in conn}
+        seen = [False] * len(self.amplicon_intervals)
+        for ai in range(len(self.amplicon_intervals)):
+            if seen[ai]:
+                continue
+            label = self.amplicon_intervals[ai][3]
+            queue = [ai]
+            while queue:
+                cur = queue.pop(0)
+                seen[cur] = True
+                self.amplicon_intervals[cur][3] = label
+                for (p, q) in self.amplicon_interval_connections:
+                    if p == cur and not seen[q]:
+                        queue.append(q)
+                    elif q == cur and not seen[p]:
+                        queue.append(p)
+        logging.debug(_t() + "There are %d amplicon intervals after merging." % len(self.amplicon_intervals))
+
+    def addbp(self, bp_, bpr_, bp_stats_, ccid):
+        """Append a breakpoint, or merge its reads into the first one within 200 bp at both ends (ibg:326-340)."""
+        for k, bp in enumerate(self.new_bp_list):
+            if bp[0] == bp_[0] and bp[3] == bp_[3] and bp[2] == bp_[2] and bp[5] == bp_[5] and \
+                    abs(bp[1] - bp_[1]) < 200 and abs(bp[4] - bp_[4]) < 200:
+                bp[-1] |= set(bpr_)
+                return k
+        self.new_bp_list.append(bp_ + [bpr_])
+        self.new_bp_ccids.append(ccid)
+        self.new_bp_stats.append(bp_stats_)
+        return len(self.new_bp_list) - 1
+
+    # -- candidate clusters -> breakpoints ---------------------------------------------------------
+    def _read_tuples(self, c: Candidates, idx):
+        names = self.rec.names
+        return [(names[r], int(i), int(j)) for r, i, j in zip(c.read[idx], c.i[idx], c.j[idx])]
+
+    def _call_breakpoints(self, c: Candidates, advance_subcluster: bool):
+        """Cluster the candidates and yield (bp list, support tuples, stats) for every accepted (sub)cluster.
+
+        ``advance_subcluster`` is False inside the interval BFS, where the reference never increments its
+        sub-cluster counter (ibg:442-457, Appendix A Q4), and True in find_breakpoints / find_smalldel_breakpoints.
+        """
+        chroms = self.rec.header_chroms
+        floor = max(self.normal_cov * self.min_bp_cov_factor, 3.0)
+        for cl in cluster_bp_list(c, self.min_cluster_cutoff, self.max_breakpoint_distance_cutoff):
+            logging.debug(_t() + "New cluster of size %d." % (len(cl)))
+            if len(cl) < self.min_cluster_cutoff:
+                continue
+            sub = 0
+            rest = cl
+            while len(rest) >= self.min_cluster_cutoff:
+                head = rest[0]
+                p1, p2, sup, st, rest = bpc2bp(c, rest, self.min_bp_match_cutoff_)
+                tuples = self._read_tuples(c, sup)
+                n_sup = len(set(tuples))
+                if (sub == 0 and n_sup >= self.min_cluster_cutoff) or n_sup >= floor:
+                    bp = [chroms[c.c1[head]], p1, _ORI[c.o1[head]], chroms[c.c2[head]], p2, _ORI[c.o2[head]],
+                          (self.rec.names[c.read[head]], int(c.i[head]), int(c.j[head])), int(c.gap[head]),
+                          int(c.swapped[head])]
+                    yield bp, tuples, st
+                if advance_subcluster:
+                    sub += 1
+
+    # -- BFS helpers ---------------------------------------------------------------------------------
+    def _reachable_segments(self, chrom, si, ei):
+        """CN segments outside [si, ei] reached from it through chimeric reads, as
+        ``{chr: {cni: set(read names)}}`` with the reference's key and set-insertion order (ibg:369-384)."""
+        T = self._chim
+        tid = self._tid_of[chrom]
+        if tid not in self._seg_tids:
+            raise KeyError(chrom)                       # self.chimeric_alignments_seg[chr] at ibg:371
+        lo = np.searchsorted(self._e_key, tid * (1 << 32) + si, side="left")
+        hi = np.searchsorted(self._e_key, tid * (1 << 32) + ei + 1, side="left")
+        reads_t = T.read[self._e_row[lo:hi]]            # visiting order: cni ascending, then append order
+        if len(reads_t) == 0:
+            return {}
+        u, first = np.unique(reads_t, return_index=True)
+        U = u[np.argsort(first, kind="stable")]         # every read once, in first-visit order
+        cnt = T.off[U + 1] - T.off[U]
+        own = np.repeat(np.arange(len(U)), cnt)
+        rows = np.repeat(T.off[U], cnt) + (np.arange(len(own)) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+        return self._reach_dict(U, rows, own, T.tid[rows], tid, si, ei)
+
+    def _reach_dict(self, U, rows, own, t_rows, tid, si, ei):
+        T = self._chim
+        names = self._chim_names
+        chroms = self.rec.header_chroms
+        c0, c1 = T.cni0[rows], T.cni1[rows]
+        v0 = (c0 >= 0) & ((t_rows != tid) | (c0 <= si) | (c0 >= ei))
+        v1 = (c1 >= 0) & (c1 != c0) & ((t_rows != tid) | (c1 <= si) | (c1 >= ei))
+        pos = np.arange(len(rows))
+        e_pos = np.concatenate([pos[v0], pos[v1]])
+        e_t = np.concatenate([t_rows[v0], t_rows[v1]])
+        e_j = np.concatenate([c0[v0], c1[v1]])
+        if len(e_pos) == 0:
+            return {}
+        o = np.argsort(e_pos, kind="stable")           # traversal order: visiting read, then segment
+        e_pos, e_t, e_j = e_pos[o], e_t[o], e_j[o]
+        e_read = U[own[e_pos]]
+        # chromosome key order = first appearance
+        ut, ft = np.unique(e_t, return_index=True)
+        chrom_order = ut[np.argsort(ft, kind="stable")]
+        reach: Dict[str, Dict[int, set]] = {}
+        key = e_t * (1 << 32) + e_j
+        ko = np.argsort(key, kind="stable")            # inside a (chr, cni) key: traversal order preserved
+        ks = key[ko]
+        bounds = np.nonzero(np.diff(ks))[0] + 1
+        starts = np.concatenate([[0], bounds])
+        ends = np.concatenate([bounds, [len(ks)]])
+        per_key = {}
+        for s, e in zip(starts, ends):
+            rr = e_read[ko[s:e]]
+            _, f = np.unique(rr, return_index=True)
+            ordered = rr[np.sort(f)]                    # each read once, in first-visit order
+            per_key[int(ks[s])] = set([names[r] for r in ordered])
+        for t in chrom_order:
+            reach[chroms[t]] = {}
+        for k, st_ in per_key.items():
+            reach[chroms[k >> 32]][k & 0xFFFFFFFF] = st_
+        return reach
+
+    def find_interval_i(self, ai, ccid):
+        """Breadth-first search for intervals connected to interval ``ai`` by breakpoint edges (ibg:343-673)."""
+        by = self.cns_intervals_by_chr
+        half = int(self.max_seq_len / 2)
+        D = self.interval_delta
+        T = self._chim
+        queue = [ai]
+        while queue:
+            cur = queue.pop(0)
+            chrom, s, e = self.amplicon_intervals[cur][:3]
+            if self.amplicon_intervals[cur][3] == -1:
+                self.amplicon_intervals[cur][3] = ccid
+            logging.debug(_t() + "\t\tNext amplicon interval %d: %s." % (cur, self.amplicon_intervals[cur]))
+            try:
+                si = self.pos2cni(chrom, s)[0]
+                ei = self.pos2cni(chrom, e)[0]
+            except Exception:
+                continue
+            reach = self._reachable_segments(chrom, si, ei)
+            for c in list(reach):
+                for j in [j for j in reach[c] if len(reach[c][j]) < self.min_cluster_cutoff]:
+                    del reach[c][j]
+                if not reach[c]:
+                    del reach[c]
+            refined, refined_bps = [], []
+            for c in reach:
+                bins = sorted(reach[c])
+                groups, names, first = [], set(), 0
+                for k in range(len(bins) - 1):
+                    names |= reach[c][bins[k]]
+                    if bins[k + 1] - bins[k] > 2 or by[c][bins[k + 1]][1] - by[c][bins[k]][2] > self.max_seq_len:
+                        groups.append((bins[first], bins[k], names))
+                        first = k + 1
+                        names = set()
+                names |= reach[c][bins[-1]]
+                groups.append((bins[first], bins[-1], names))
+                for (b0, b1, grp_names) in groups:
+                    ns, ne = by[c][b0][1], by[c][b1][2]
+                    tgt = [c, ns, ne]
+                    here = self.amplicon_intervals[cur]
+                    reads = np.array([self._chim_index[rn] for rn in grp_names], dtype=np.int64)   # set order (Q21)
+                    cands = candidates_between(T, reads, (self._tid_of[c], ns, ne),
+                                               (self._tid_of[here[0]], here[1], here[2]), self._chr_rank,
+                                               self.min_bp_match_cutoff_, 20)
+                    cands.read = T.name_id[cands.read]
+                    logging.debug(_t() + "\t\tFound %d reads connecting the two intervals." % len(cands))
+                    found = []
+                    for bp, tuples, st in self._call_breakpoints(cands, advance_subcluster=False):
+                        k = self.addbp(bp, set(tuples), st, ccid)
+                        if k not in found:
+                            found.append(k)
+                    inside, outside = [], []
+                    for k in found:
+                        bp = self.new_bp_list[k][:6]
+                        e1, e2 = [bp[0], bp[1], bp[1]], [bp[3], bp[4], bp[4]]
+                        try:
+                            if interval_overlap(e1, here) and interval_overlap(e2, tgt):
+                                inside.append([self.pos2cni(bp[3], bp[4])[0], bp[4], k])
+                            elif interval_overlap(e2, here) and interval_overlap(e1, tgt):
+                                inside.append([self.pos2cni(bp[0], bp[1])[0], bp[1], k])
+                            else:
+                                logging.warning(_t() + "\t\tExact breakpoint outside amplicon interval.")
+                                o1, o2 = interval_overlap(e1, tgt), interval_overlap(e2, tgt)
+                                if o1:
+                                    inside.append([self.pos2cni(bp[0], bp[1])[0], bp[1], k])
+                                else:
+                                    outside.append([bp[0], self.pos2cni(bp[0], bp[1])[0], bp[1], k])
+                                if o2:
+                                    inside.append([self.pos2cni(bp[3], bp[4])[0], bp[4], k])
+                                else:
+                                    outside.append([bp[3], self.pos2cni(bp[3], bp[4])[0], bp[4], k])
+                        except Exception:
+                            pass
+                    if not found:
+                        continue
+                    inside.sort(key=lambda t: (t[0], t[1]))
+                    outside.sort(key=lambda t: (chr_idx[t[0]], t[1], t[2]))
+                    segs = by[c]
+                    gain = self.cn_gain
+
+                    def split_inside(k):
+                        nil, ncn = segs[inside[k + 1][0]][1], segs[inside[k + 1][0]][3]
+                        lir, lcn = segs[inside[k][0]][2], segs[inside[k][0]][3]
+                        amp = ncn >= gain or lcn >= gain
+                        dpos = inside[k + 1][1] - inside[k][1]
+                        return (inside[k + 1][0] - inside[k][0] > 2 or nil - lir > self.max_seq_len / 2 or
+                                dpos > self.max_seq_len or (not amp and nil - lir > 2 * D) or (not amp and dpos > 3 * D))
+
+                    first = 0
+                    for k in range(len(inside) - 1):
+                        if not split_inside(k):
+                            continue
+                        f, z = inside[first], inside[k]
+                        lir = segs[z[0]][2]
+                        l = max((f[1] if not segs[f[0]][3] >= gain else segs[f[0]][1]) - D, segs[0][1])
+                        r = min((z[1] if not segs[z[0]][3] >= gain else lir) + D, segs[-1][2])
+                        if segs[f[0]][3] and f[1] - half > l:            # Q3: CN value used as a truth value
+                            l = f[1] - half
+                        if z[1] + half < r:
+                            r = z[1] + half
+                        if not self.pos2cni(c, l):
+                            l = segs[f[0]][1]
+                        if not self.pos2cni(c, r):
+                            r = lir
+                        refined.append([c, l, r, -1])
+                        refined_bps.append([inside[j][2] for j in range(first, k + 1)])
+                        first = k + 1
+                    if inside:
+                        f, z = inside[first], inside[-1]
+                        l = max((f[1] if not segs[f[0]][3] >= gain else segs[f[0]][1]) - D, segs[0][1])
+                        r = min((z[1] if not segs[z[0]][3] >= gain else segs[z[0]][2]) + D, segs[-1][2])
+                        if f[1] - half > l:
+                            l = f[1] - half > l                         # Q2: the comparison result is stored
+                        if z[1] + half < r:
+                            r = z[1] + half
+                        if not self.pos2cni(c, l):
+                            l = segs[f[0]][1]
+                        if not self.pos2cni(c, r):
+                            r = segs[z[0]][2]
+                        refined.append([c, l, r, -1])
+                        refined_bps.append([inside[j][2] for j in range(first, len(inside))])
+
+                    def split_outside(k):
+                        a, b = outside[k], outside[k + 1]
+                        nil, ncn = by[b[0]][b[1]][1], by[b[0]][b[1]][3]
+                        lir, lcn = by[a[0]][a[1]][2], by[a[0]][a[1]][3]
+                        amp = ncn >= gain or lcn >= gain
+                        return (b[0] != a[0] or b[1] - a[1] > 2 or nil - lir > self.max_seq_len / 2 or
+                                b[2] - a[2] > self.max_seq_len or (not amp and nil - lir > 2 * D) or
+                                (not amp and b[2] - a[2] > 3 * D))
+
+                    first = 0
+                    for k in range(len(outside) - 1):
+                        if not split_outside(k):
+                            continue
+                        f, z = outside[first], outside[k]
+                        lir = by[z[0]][z[1]][2]
+                        l = max((f[2] if not by[f[0]][f[1]][3] >= gain else by[f[0]][f[1]][1]) - D, by[f[0]][0][1])
+                        r = min((z[2] if not by[z[0]][z[1]][3] >= gain else lir) + D, by[z[0]][-1][2])
+                        if f[2] - half > l:
+                            l = f[2] - half
+                        if z[2] + half < r:
+                            r = z[2] + half
+                        if not self.pos2cni(f[0], l):
+                            l = by[f[0]][f[1]][1]
+                        if not self.pos2cni(z[0], r):
+                            r = lir
+                        refined.append([f[0], l, r, -1])
+                        refined_bps.append([])
+                        first = k + 1
+                    if outside:
+                        f, z = outside[first], outside[-1]
+                        l = max((f[2] if not by[f[0]][f[1]][3] >= gain else by[f[0]][f[1]][1]) - D, by[f[0]][0][1])
+                        r = min((z[2] if not by[z[0]][z[1]][3] >= gain else by[z[0]][z[1]][2]) + D, by[z[0]][-1][2])
+                        if f[2] - half > l:
+                            l = f[2] - half
+                        if z[2] + half < r:
+                            r = z[2] + half
+                        if not self.pos2cni(f[0], l):
+                            l = by[f[0]][f[1]][1]
+                        if not self.pos2cni(f[0], r):
+                            r = by[f[0]][z[1]][2]
+                        refined.append([f[0], l, r, -1])
+                        refined_bps.append([])
+
+            conn = self.amplicon_interval_connections
+            for ni, cand_iv in enumerate(refined):
+                hit, parts = interval_exclusive(cand_iv, self.amplicon_intervals)
+                if not parts:
+                    for k in refined_bps[ni]:
+                        bp = self.new_bp_list[k][:6]
+                        for o in hit:
+                            if (o != cur and interval_overlap([bp[0], bp[1], bp[1]], self.amplicon_intervals[o])) or \
+                                    interval_overlap([bp[3], bp[4], bp[4]], self.amplicon_intervals[o]):       # Q5
+                                conn.setdefault((min(cur, o), max(cur, o)), set()).add(k)
+                    for o in hit:
+                        if o != cur and self.amplicon_intervals[o][3] < 0:
+                            queue.append(o)
+                else:
+                    for part in parts:
+                        nai = len(self.amplicon_intervals)
+                        self.amplicon_intervals.append(part)
+                        logging.debug(_t() + "\t\tAdded new interval %s to the amplicon interval list." % part)
+                        conn[(cur, nai)] = set()
+                        for k in refined_bps[ni]:
+                            if not hit:
+                                conn[(cur, nai)].add(k)
+                                continue
+                            bp = self.new_bp_list[k][:6]
+                            for o in hit:
+                                if interval_overlap([bp[0], bp[1], bp[1]], self.amplicon_intervals[o]) or \
+                                        interval_overlap([bp[3], bp[4], bp[4]], self.amplicon_intervals[o]):
+                                    conn.setdefault((min(cur, o), max(cur, o)), set()).add(k)
+                                else:
+                                    conn[(cur, nai)].add(k)
+                        queue.append(nai)
+
+    def _add_clustered(self, cands: Candidates):
+        """Tail shared by find_breakpoints and find_smalldel_breakpoints (ibg:691-718, ibg:775-802)."""
+        for bp, tuples, st in self._call_breakpoints(cands, advance_subcluster=True):
+            io1 = interval_overlap_l([bp[0], bp[1], bp[1]], self.amplicon_intervals)
+            io2 = interval_overlap_l([bp[3], bp[4], bp[4]], self.amplicon_intervals)
+            if io1 >= 0 and io2 >= 0:
+                assert self.amplicon_intervals[io1][3] == self.amplicon_intervals[io2][3]
+                k = self.addbp(bp, set(tuples), st, self.amplicon_intervals[io1][3])
+                self.amplicon_interval_connections.setdefault((min(io1, io2), max(io1, io2)), set()).add(k)
+
+    # ---- A6 ----------------------------------------------------------------------------------
+    def find_smalldel_breakpoints(self):
+        """Large deletions inside single alignment records (ibg:721-802), from the gap rows of coral_cigar_scan."""
+        dr = self.rec
+        sc = self.scan()
+        g = sc.gaps
+        parts = []
+        if len(g):
+            g_rec = g[:, 0].astype(np.int64)
+            g_tid, g_pos, g_end = dr.h_tid[g_rec], dr.h_pos[g_rec], dr.h_end[g_rec]
+            for ai, iv in enumerate(self.amplicon_intervals):
+                t = self._tid_of[iv[0]]
+                m = (g_tid == t) & (g_pos < iv[2] + 1) & (g_end > iv[1])       # a record in two intervals counts twice (Q11)
+                parts.append(np.nonzero(m)[0])
+        sel = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
+        cands = Candidates()
+        if len(sel):
+            rec = g[sel, 0].astype(np.int64)
+            b0, b1 = g[sel, 4], g[sel, 5]
+            nid = dr.h_name_id[rec].astype(np.int64)
+            nxt, prv = g[sel, 3].astype(np.int64), g[sel, 2].astype(np.int64)
+            # dict insertion order = first appearance of the name; list order = appearance order
+            u, first, inv = np.unique(nid, return_index=True, return_inverse=True)
+            rank = np.empty(len(u), dtype=np.int64)
+            rank[np.argsort(first, kind="stable")] = np.arange(len(u))
+            o = np.argsort(rank[inv], kind="stable")
+            grp = rank[inv][o]
+            k_in = np.arange(len(o)) - np.searchsorted(grp, grp, side="left")
+            names = dr.names
+            chroms = dr.header_chroms
+            lia = self.large_indel_alignments
+            for q, kk in zip(o, k_in):
+                r = rec[q]
+                lia.setdefault(names[nid[q]], []).append([chroms[dr.h_tid[r]], int(nxt[q]), int(prv[q]), int(b0[q]),
+                                                         int(b1[q]), int(dr.h_mapq[r])])
+            a = nxt[o]
+            b = np.minimum(prv[o], a)                                            # aliasing swap (Q7)
+            tid = dr.h_tid[rec[o]].astype(np.int64)
+            z = np.zeros(len(o), dtype=np.int64)
+            cands = Candidates(c1=tid, p1=a, o1=z + 1, c2=tid, p2=b, o2=z, read=nid[o], i=k_in, j=k_in, gap=z, swapped=z,
+                               mqa=z - 1, mqb=z - 1)
+        logging.info(_t() + "Fetched %d reads with large indels in CIGAR." % (len(self.large_indel_alignments)))
+        self._add_clustered(cands)
+
+    # ---- A7 ----------------------------------------------------------------------------------
+    def find_breakpoints(self):
+        """Breakpoints from chimeric alignments inside the amplicon intervals (ibg:676-718)."""
+        T = self._chim
+        ivs = [(self._tid_of[iv[0]], iv[1], iv[2]) for iv in self.amplicon_intervals]
+        cands = candidates_within(T, ivs, self._chr_rank, self.min_bp_match_cutoff_, 20, 100)
+        cands.read = T.name_id[cands.read]
+        logging.debug(_t() + "Found %d reads with new breakpoints." % (len(cands)))
+        self._add_clustered(cands)
+
+    # ---- A9 ----------------------------------------------------------------------------------
+    def build_graph(self, graph_class=BreakpointGraph):
+        """Split the intervals at breakpoint ends and assemble one BreakpointGraph per amplicon (ibg:864-1016)."""
+        cuts: Dict[int, list] = {}
+        for k, bp in enumerate(self.new_bp_list):
+            for ai, seg in enumerate(self.amplicon_intervals):
+                for (ci, pi, oi) in ((0, 1, 2), (3, 4, 5)):
+                    if bp[ci] == seg[0] and seg[1] < bp[pi] < seg[2]:
+                        if bp[oi] == '+':
+                            cuts.setdefault(ai, []).append((bp[pi], bp[pi] + 1, k, pi, '+'))
+                        if bp[oi] == '-':
+                            cuts.setdefault(ai, []).append((bp[pi] - 1, bp[pi], k, pi, '-'))
+        nxt = 1
+        for seg in self.amplicon_intervals:
+            if seg[3] not in self.ccid2id:
+                self.ccid2id[seg[3]] = nxt
+                nxt += 1
+        for _ in range(len(self.ccid2id)):
+            self.lr_graph.append(graph_class())
+        graph_of = lambda seg: self.lr_graph[self.ccid2id[seg[3]] - 1]
+        for ai in cuts:
+            cuts[ai].sort(key=lambda t: t[0])
+            seg = self.amplicon_intervals[ai]
+            g, c = graph_of(seg), seg[0]
+            prev_cut = None
+            for cut in cuts[ai]:
+                if prev_cut is None:
+                    left = seg[1]
+                elif cut[0] > prev_cut[0]:
+                    left = prev_cut[1]
+                else:
+                    prev_cut = cut
+                    continue
+                g.add_node((c, left, '-'))
+                g.add_node((c, cut[0], '+'))
+                g.add_node((c, cut[1], '-'))
+                g.add_sequence_edge(c, left, cut[0])
+                g.add_concordant_edge(c, cut[0], '+', c, cut[1], '-')
+                prev_cut = cut
+            g.add_node((c, cuts[ai][-1][1], '-'))
+            g.add_node((c, seg[2], '+'))
+            g.add_sequence_edge(c, cuts[ai][-1][1], seg[2])
+        for ai, seg in enumerate(self.amplicon_intervals):
+            if ai not in cuts:
+                g = graph_of(seg)
+                g.add_node((seg[0], seg[1], '-'))
+                g.add_node((seg[0], seg[2], '+'))
+                g.add_sequence_edge(seg[0], seg[1], seg[2])
+        for g in self.lr_graph:
+            g.sort_edges()
+        for seg in self.amplicon_intervals:
+            g = graph_of(seg)
+            g.amplicon_intervals.append([seg[0], seg[1], seg[2]])
+            g.add_endnode((seg[0], seg[1], '-'))
+            g.add_endnode((seg[0], seg[2], '+'))
+        for k, bp in enumerate(self.new_bp_list):
+            io1 = interval_overlap_l([bp[0], bp[1], bp[1]], self.amplicon_intervals)
+            io2 = interval_overlap_l([bp[3], bp[4], bp[4]], self.amplicon_intervals)
+            assert self.amplicon_intervals[io1][3] == self.amplicon_intervals[io2][3]
+            cc = self.amplicon_intervals[io1][3]
+            if cc != self.new_bp_ccids[k]:
+                self.new_bp_ccids[k] = cc
+            self.lr_graph[self.ccid2id[cc] - 1].add_discordant_edge(bp[0], bp[1], bp[2], bp[3], bp[4], bp[5],
+                                                                     lr_count=len(bp[-1]), reads=bp[-1])
+        for srci, srce in enumerate(self.source_edges):
+            self.lr_graph[self.ccid2id[self.source_edge_ccids[srci]] - 1].add_source_edge(srce[3], srce[4], srce[5])
+
+    # ---- A10 ---------------------------------------------------------------------------------
+    def assign_cov(self):
+        """Long-read coverage of every sequence edge and read support of every concordant edge (ibg:1019-1056)."""
+        todo = [(g, k) for g in self.lr_graph for k, e in enumerate(g.sequence_edges) if e[5] == -1]
+        if todo:
+            n_reads, n_bases = self._coverage([g.sequence_edges[k][:3] for g, k in todo])
+            for (g, k), nr, nb in zip(todo, n_reads, n_bases):
+                g.sequence_edges[k][5] = int(nr)
+                g.sequence_edges[k][6] = int(nb)
+        cut = self.min_bp_match_cutoff_
+        edges = [(g, e) for g in self.lr_graph for e in g.concordant_edges]
+        pts = []
+        for g, e in edges:
+            t1, t2 = self._tid_of[e[0]], self._tid_of[e[3]]
+            pts += [(t1, e[1]), (t2, e[4]), (t1, e[1] - cut - 1), (t2, e[4] + cut)]
+        cover = kernels.point_cover(self.rec, pts) if pts else []
+        nid = self.rec.h_name_id
+        names = self.rec.names
+        for q, (g, e) in enumerate(edges):
+            rls, rrs, rls1, rrs1 = (np.unique(nid[cover[4 * q + d]]) for d in range(4))
+            rbps = set()
+            for node in ((e[0], e[1], e[2]), (e[3], e[4], e[5])):
+                for k in g.nodes[node][2]:
+                    for t in g.discordant_edges[k][10]:
+                        rbps.add(t[0])
+            both = np.intersect1d(np.intersect1d(rls, rrs, assume_unique=True),
+                                  np.intersect1d(rls1, rrs1, assume_unique=True), assume_unique=True)
+            e[9] = set([names[i] for i in np.union1d(rls, rrs)])
+            e[8] = sum(1 for i in both if names[i] not in rbps) if rbps else int(len(both))
+
+    def compute_path_constraints(self):
+        raise NotImplementedError("path constraints belong to the cycle-decomposition step (SURVEY.md §8(f) item 2)")
+
+    def closebam(self):
+        self.lr_bamfh.close()
+
+
+class _LazyReadLength(dict):
+    """``read name -> query length`` for reads with a primary record; built from arrays on first use."""
+
+    def __init__(self, names, rl, has):
+        super().__init__()
+        self._names, self._rl, self._has, self._done = names, rl, has, False
+
+    def _fill(self):
+        if not self._done:
+            self._done = True
+            names, rl = self._names, self._rl
+            dict.update(self, {names[i]: int(rl[i]) for i in self._has})
+
+    def __len__(self):
+        return len(self._has)
+
+    def __contains__(self, k):
+        self._fill()
+        return dict.__contains__(self, k)
+
+    def __getitem__(self, k):
+        self._fill()
+        return dict.__getitem__(self, k)
+
+    def __iter__(self):
+        self._fill()
+        return dict.__iter__(self)
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+
+class _SegIndexView:
+    """``chimeric_alignments_seg[chr][cni] -> [read names]`` view over the sorted inverted index."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    def as_dict(self):
+        o = self._o
+        T = o._chim
+        chroms = o.rec.header_chroms
+        out: Dict[str, Dict[int, list]] = {}
+        # chromosome key order: first appearance along (read, segment) order
+        for t in o._seg_tids:
+            out[chroms[t]] = {}
+        for row, cni in zip(o._e_row, o._e_cni):
+            out[chroms[T.tid[row]]].setdefault(int(cni), []).append(o._chim_names[T.read[row]])
+        return out
+
+    def __contains__(self, c):
+        o = self._o
+        return c in o._tid_of and o._tid_of[c] in o._seg_tids
+
+
+def build_graph_from_records(records, seedfile, cn_seg, output_prefix=None, min_bp_support=1.0, output_bp=False,
+                             graph_class=BreakpointGraph):
+    """The call sequence of reconstruct_graph (ibg:1349-1394) on already-decoded records."""
+    b2bn = bam_to_breakpoint_nanopore(None, seedfile, records=records)
+    b2bn.min_bp_cov_factor = min_bp_support
+    logging.info(_t() + "Opened LR bam files.")
+    b2bn.read_cns(cn_seg)
+    logging.info(_t() + "Completed parsing CN segment files.")
+    b2bn.fetch()
+    logging.info(_t() + "Completed fetching reads containing breakpoints.")
+    b2bn.hash_alignment_to_seg()
+    logging.info(_t() + "Completed hashing chimeric reads to CN segments.")
+    b2bn.find_amplicon_intervals()
+    logging.info(_t() + "Completed finding amplicon intervals.")
+    b2bn.find_smalldel_breakpoints()
+    logging.info(_t() + "Completed finding small del breakpoints.")
+    b2bn.find_breakpoints()
+    logging.info(_t() + "Completed finding all discordant breakpoints.")
+    b2bn.build_graph(graph_class)
+    logging.info(_t() + "Breakpoint graph built for all amplicons.")
+    if output_bp:
+        for gi in range(len(b2bn.lr_graph)):
+            bp_stats_i = []
+            for de in b2bn.lr_graph[gi].discordant_edges:
+                for bpi in range(len(b2bn.new_bp_list)):
+                    if de[:6] == b2bn.new_bp_list[bpi][:6]:
+                        bp_stats_i.append(b2bn.new_bp_stats[bpi])
+                        break
+            if output_prefix is not None:
+                output_breakpoint_info_lr(b2bn.lr_graph[gi], output_prefix + "_amplicon" + str(gi + 1) + "_breakpoints.txt",
+                                          bp_stats_i)
+        logging.info(_t() + "Wrote breakpoint information, for all amplicons, to %s." % (str(output_prefix) + '_amplicon*_breakpoints.txt'))
+    else:
+        b2bn.assign_cov()
+        logging.info(_t() + "Fetched read coverage for all sequence and concordant edges.")
+        for g in b2bn.lr_graph:
+            compute_cn_lr(g, b2bn.normal_cov)
+        logging.info(_t() + "Computed CN for all edges.")
+        if output_prefix is not None:
+            for gi in range(len(b2bn.lr_graph)):
+                output_breakpoint_graph_lr(b2bn.lr_graph[gi], output_prefix + "_amplicon" + str(gi + 1) + "_graph.txt")
+        logging.info(_t() + "Wrote breakpoint graph for all complicons to %s." % (str(output_prefix) + '_amplicon*_graph.txt'))
+    return b2bn
+
+
+def reconstruct_graph(args):
+    """Same contract as the reference's reconstruct_graph(args) (ibg:1333-1395)."""
+    global_names.TSTART = time.time()
+    log_fn = "infer_breakpoint_graph.log"
+    if getattr(args, "log_fn", None):
+        log_fn = args.log_fn
+    logging.basicConfig(filename=log_fn, filemode='w', level=logging.DEBUG, format='[%(name)s:%(levelname)s]\t%(message)s')
+    logging.info("Python version " + sys.version + "\n")
+    commandstring = 'Commandline: '
+    for arg in sys.argv:
+        commandstring += ('"{}" '.format(arg) if ' ' in arg else "{} ".format(arg))
+    logging.info(_t() + commandstring)
+    from .bam import decode_bam
+    from .records import DeviceRecords
+    records = DeviceRecords(decode_bam(args.lr_bam), getattr(args, "device", "cuda:0"))
+    return build_graph_from_records(records, args.cnv_seed, args.cn_seg, args.output_prefix, args.min_bp_support,
+                                    args.output_bp)
+
+
+def print_complete_message():
+    logging.info(_t() + "Total runtime.")

@@ -1,26 +1,37 @@
-"""Thin Python wrappers over the C ABI (include/coral_hip.h): allocate outputs with torch, launch on the
-current HIP stream, give results the deterministic order the host logic expects."""
+"""Python wrappers over the C ABI (include/coral_hip.h).
+
+Each public function = the local launch on this process's shard of records (``_*_local``: allocate outputs with
+torch, launch on the current HIP stream) + the exchange step when records are sharded over several GPUs
+(coral_amd.sharding: all-gather-v of candidate rows, all-reduce of the integer per-segment sums) + the
+deterministic ordering the host logic relies on.  Integer sums and sorted rows make the results identical for
+any number of shards.
+"""
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Sequence, Tuple
+from typing import List, Sequence, Tuple
 
 import numpy as np
 import torch
 
 from . import _lib
-from .records import DeviceRecords
+
+PROFILE = {}      # bench.py: PROFILE["scan_ms"] = [] collects (start, end) HIP events around every cigar_scan launch
 
 
 class ScanResult:
-    """Per-record CIGAR summaries (device tensors) and the large-gap rows (host, reference order)."""
+    """Per-record CIGAR summaries of the local shard (device tensors) and the large-gap rows of ALL shards.
+
+    gaps: int64 [K, 6] = record ordinal (global), op index of the next block, previous block end, next block start,
+    first block start, last block end of that record; sorted by (record, op index) — the reference's order.
+    """
 
     def __init__(self, mbases, qinfer, blk_first, blk_last, gaps):
         self.mbases, self.qinfer, self.blk_first, self.blk_last = mbases, qinfer, blk_first, blk_last
-        self.gaps = gaps      # int32 [K, 4]: record, op index, previous block end, next block start
+        self.gaps = gaps
 
 
-def cigar_scan(dr: DeviceRecords, min_gap: int = 600, min_mapq: int = 20, gap_cap: int = 1 << 16) -> ScanResult:
+def _scan_local(dr, min_gap: int, min_mapq: int, gap_cap: int):
     L = _lib.lib()
     dev = dr.device
     n = dr.n
@@ -32,18 +43,38 @@ def cigar_scan(dr: DeviceRecords, min_gap: int = 600, min_mapq: int = 20, gap_ca
     while True:
         gaps = torch.empty((gap_cap, 4), dtype=torch.int32, device=dev)
         cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        prof = PROFILE.get("scan_ms")
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(dev))
         _lib.check(L.coral_cigar_scan(C.byref(rs), min_gap, min_mapq, mb.data_ptr(), qi.data_ptr(), b0.data_ptr(),
                                       b1.data_ptr(), gaps.data_ptr(), cnt.data_ptr(), gap_cap, dr.stream()),
                    "coral_cigar_scan")
+        if prof is not None:
+            e1.record(torch.cuda.current_stream(dev))
+            prof.append((e0, e1))
         k = int(cnt.item()) & 0xFFFFFFFF
         if k <= gap_cap:
             break
         gap_cap = 1 << int(np.ceil(np.log2(k + 1)))
-    g = gaps[:k].cpu().numpy()
-    if k:
-        order = np.lexsort((g[:, 1], g[:, 0]))       # (record ordinal, op index): the reference's iteration order
-        g = g[order]
-    return ScanResult(mb[:n], qi[:n], b0[:n], b1[:n], g)
+    g = gaps[:k].to(torch.int64)
+    rows = torch.cat([g, b0[:n][g[:, 0]].to(torch.int64)[:, None], b1[:n][g[:, 0]].to(torch.int64)[:, None]], dim=1) \
+        if k else torch.zeros((0, 6), dtype=torch.int64, device=dev)
+    return mb[:n], qi[:n], b0[:n], b1[:n], rows
+
+
+def cigar_scan(dr, min_gap: int = 600, min_mapq: int = 20, gap_cap: int = 1 << 16, _worker=False) -> ScanResult:
+    from . import sharding
+    if dr.world > 1 and not _worker:
+        sharding.command(dr, ("scan", min_gap, min_mapq, gap_cap))
+    mb, qi, b0, b1, rows = _scan_local(dr, min_gap, min_mapq, gap_cap)
+    rows[:, 0] += dr.lo
+    if dr.world > 1:
+        rows = sharding.allgather_rows(dr, rows)
+    g = rows.cpu().numpy()
+    if len(g):
+        g = g[np.lexsort((g[:, 1], g[:, 0]))]      # (record ordinal, op index): the reference's iteration order
+    return ScanResult(mb, qi, b0, b1, g)
 
 
 def _disjoint_batches(segs: np.ndarray) -> List[np.ndarray]:
@@ -64,19 +95,14 @@ def _disjoint_batches(segs: np.ndarray) -> List[np.ndarray]:
     return [np.array(b, dtype=np.int64) for b in batches]
 
 
-def segment_coverage(dr: DeviceRecords, scan: ScanResult, segs: Sequence[Tuple[int, int, int]]):
-    """(n_reads, n_bases) int64 arrays for half-open segments (tid, start, end); any order, may overlap.
-
-    n_bases already excludes aligned non-ACGT bases (what pysam count_coverage leaves out of its four arrays).
-    """
+def _coverage_local(dr, scan: ScanResult, sg: np.ndarray) -> torch.Tensor:
+    """int64 [2, S] (n_reads, n_bases) of the local shard for sorted-or-not, possibly overlapping segments."""
     L = _lib.lib()
-    S = len(segs)
-    n_reads = np.zeros(S, dtype=np.int64)
-    n_bases = np.zeros(S, dtype=np.int64)
-    if S == 0 or dr.n == 0:
-        return n_reads, n_bases
-    sg = np.asarray(segs, dtype=np.int64).reshape(S, 3)
+    S = len(sg)
     dev = dr.device
+    out_all = torch.zeros((2, S), dtype=torch.int64, device=dev)
+    if dr.n == 0:
+        return out_all
     rs = dr.c_struct()
     strad = torch.empty(dr.n, dtype=torch.int32, device=dev)
     for batch in _disjoint_batches(sg):
@@ -90,9 +116,27 @@ def segment_coverage(dr: DeviceRecords, scan: ScanResult, segs: Sequence[Tuple[i
                                             t.data_ptr(), s.data_ptr(), e.data_ptr(), out[0].data_ptr(),
                                             out[1].data_ptr(), strad.data_ptr(), cnt.data_ptr(), dr.stream()),
                    "coral_segment_coverage")
-        o = out.cpu().numpy()
-        n_reads[batch] = o[0]
-        n_bases[batch] = o[1]
+        out_all[:, torch.tensor(batch, device=dev)] = out
+    return out_all
+
+
+def segment_coverage(dr, scan: ScanResult, segs: Sequence[Tuple[int, int, int]], _worker=False):
+    """(n_reads, n_bases) int64 arrays for half-open segments (tid, start, end); any order, may overlap.
+
+    n_bases already excludes aligned non-ACGT bases (what pysam count_coverage leaves out of its four arrays).
+    """
+    from . import sharding
+    S = len(segs)
+    if S == 0:
+        return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+    sg = np.asarray(segs, dtype=np.int64).reshape(S, 3)
+    if dr.world > 1 and not _worker:
+        sharding.command(dr, ("coverage", sg))
+    out = _coverage_local(dr, scan, sg)
+    if dr.world > 1:
+        out = sharding.allreduce_sum(dr, out)
+    o = out.cpu().numpy()
+    n_reads, n_bases = o[0].copy(), o[1].copy()
     if len(dr.h_nonacgt_rec):
         nt = dr.h_tid[dr.h_nonacgt_rec]
         npos = dr.h_nonacgt_pos
@@ -101,15 +145,12 @@ def segment_coverage(dr: DeviceRecords, scan: ScanResult, segs: Sequence[Tuple[i
     return n_reads, n_bases
 
 
-def point_cover(dr: DeviceRecords, points: Sequence[Tuple[int, int]], pair_cap: int = 1 << 20) -> List[np.ndarray]:
-    """For every (tid, pos) the ordinals (file order) of the records with pos <= p < end."""
+def _points_local(dr, uniq: np.ndarray, pair_cap: int) -> torch.Tensor:
+    """Packed (point index << 32 | LOCAL record ordinal) pairs of the local shard, unsorted."""
     L = _lib.lib()
-    P = len(points)
-    if P == 0:
-        return []
-    pts = np.asarray(points, dtype=np.int64).reshape(P, 2)
-    uniq, inverse = np.unique(pts, axis=0, return_inverse=True)     # sorted by (tid, pos)
     dev = dr.device
+    if dr.n == 0:
+        return torch.zeros(0, dtype=torch.int64, device=dev)
     t = torch.tensor(uniq[:, 0], dtype=torch.int32, device=dev)
     p = torch.tensor(uniq[:, 1], dtype=torch.int32, device=dev)
     rs = dr.c_struct()
@@ -120,9 +161,24 @@ def point_cover(dr: DeviceRecords, points: Sequence[Tuple[int, int]], pair_cap: 
                                        cnt.data_ptr(), pair_cap, dr.stream()), "coral_point_cover")
         k = int(cnt.item()) & 0xFFFFFFFF
         if k <= pair_cap:
-            break
+            return pairs[:k]
         pair_cap = 1 << int(np.ceil(np.log2(k + 1)))
-    keys = torch.sort(pairs[:k]).values.cpu().numpy()       # (point, record ordinal) order == fetch order per point
+
+
+def point_cover(dr, points: Sequence[Tuple[int, int]], pair_cap: int = 1 << 20, _worker=False) -> List[np.ndarray]:
+    """For every (tid, pos) the ordinals (file order) of the records with pos <= p < end."""
+    from . import sharding
+    P = len(points)
+    if P == 0:
+        return []
+    pts = np.asarray(points, dtype=np.int64).reshape(P, 2)
+    if dr.world > 1 and not _worker:
+        sharding.command(dr, ("points", pts, pair_cap))
+    uniq, inverse = np.unique(pts, axis=0, return_inverse=True)     # sorted by (tid, pos)
+    pairs = _points_local(dr, uniq, pair_cap) + dr.lo                # record ordinal -> global
+    if dr.world > 1:
+        pairs = sharding.allgather_rows(dr, pairs[:, None])[:, 0]
+    keys = torch.sort(pairs).values.cpu().numpy()           # (point, record ordinal) order == fetch order per point
     pt = keys >> 32
     rec = (keys & 0xFFFFFFFF).astype(np.int64)
     bounds = np.searchsorted(pt, np.arange(len(uniq) + 1))

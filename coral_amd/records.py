@@ -21,13 +21,27 @@ class DeviceRecords:
     Host mirrors (numpy):  the same per-record fields + qlen, nm, name_id, and the tokenised SA rows.
     """
 
-    def __init__(self, rec, device="cuda:0"):
+    def __init__(self, rec, device="cuda:0", rank=0, world=1, group=None):
+        """``rank``/``world``: this process keeps records [lo, hi) of the file in HBM (a contiguous range balanced
+        by CIGAR-op count); the small host mirrors always describe the whole file."""
         self.device = torch.device(device)
         dev = self.device
-        self.n = int(rec.n)
+        self.rank, self.world, self.group = int(rank), int(world), group
+        self.n_total = int(rec.n)
         self.header_chroms = list(rec.header_chroms)
         self.header_lens = list(rec.header_lens)
-        i32 = lambda t: t.to(device=dev, dtype=torch.int32).contiguous()
+        off_all = rec.cigar_off
+        if world > 1 and self.n_total > 0:
+            total = int(off_all[-1])
+            cuts = torch.searchsorted(off_all[:-1].contiguous(), torch.tensor([total * r // world for r in range(world + 1)],
+                                                                               dtype=off_all.dtype, device=off_all.device))
+            cuts[0], cuts[-1] = 0, self.n_total
+            self.lo, self.hi = int(cuts[rank]), int(cuts[rank + 1])
+        else:
+            self.lo, self.hi = 0, self.n_total
+        lo, hi = self.lo, self.hi
+        self.n = hi - lo
+        i32 = lambda t: t[lo:hi].to(device=dev, dtype=torch.int32).contiguous()
         self.tid = i32(rec.tid)
         self.pos = i32(rec.pos)
         self.end = i32(rec.end)
@@ -35,8 +49,10 @@ class DeviceRecords:
                  ((rec.has_seq.to(torch.int64) & 1) << 24)
         self.flagmq = i32(flagmq)
         self.n_cigar = i32(rec.n_cigar)
-        self.cigar_off = rec.cigar_off.to(device=dev, dtype=torch.int64).contiguous()
-        self.cigar = rec.cigar.to(device=dev, dtype=torch.int32).contiguous()
+        c0 = int(off_all[lo]) if self.n_total else 0
+        c1 = int(off_all[hi]) if self.n_total else 0
+        self.cigar_off = (off_all[lo:hi + 1] - c0).to(device=dev, dtype=torch.int64).contiguous()
+        self.cigar = rec.cigar[c0:c1].to(device=dev, dtype=torch.int32).contiguous()
         if self.cigar.numel() == 0:
             self.cigar = torch.zeros(4, dtype=torch.int32, device=dev)
         # layout contract of include/coral_hip.h — checked on the host before any kernel can touch the arrays
@@ -67,7 +83,9 @@ class DeviceRecords:
         self.n_names = int(rec.n_names)
         self._rec = rec
         self._names: Optional[List[str]] = rec.names
-        self.total_ops = int(self.h_n_cigar.astype(np.int64).sum())
+        self.total_ops_all = int(self.h_n_cigar.astype(np.int64).sum())
+        self.total_ops = int(self.h_n_cigar[lo:hi].astype(np.int64).sum())
+        self.n_sa_local = int(self.h_sa_off[hi] - self.h_sa_off[lo]) if self.n_total else 0
         self.n_sa = int(self.h_sa.shape[0])
         t = np.arange(len(self.header_chroms))
         self.tid_lo = np.searchsorted(self.h_tid, t, side="left")
@@ -80,8 +98,8 @@ class DeviceRecords:
         return self._names
 
     def algorithmic_bytes(self) -> int:
-        """SURVEY.md §8(d):  Σ_rec (32 + 4·n_cigar) + 32·N_SA."""
-        return 32 * self.n + 4 * self.total_ops + 32 * self.n_sa
+        """SURVEY.md §8(d):  Σ_rec (32 + 4·n_cigar) + 32·N_SA  over the records this process holds."""
+        return 32 * self.n + 4 * self.total_ops + 32 * self.n_sa_local
 
     def c_struct(self) -> _lib.coral_records_t:
         return _lib.coral_records_t(self.n, self.tid.data_ptr(), self.pos.data_ptr(), self.end.data_ptr(),
@@ -91,7 +109,7 @@ class DeviceRecords:
     def stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 
-    def region(self, tid: int, start: int, stop: int) -> np.ndarray:
+    def region(self, tid: int, start: int, stop: int) -> np.ndarray:  # whole file
         """Host-side record-level region query (htslib rule pos < stop and end > start), file order."""
         lo, hi = self.tid_lo[tid], self.tid_hi[tid]
         m = (self.h_pos[lo:hi] < stop) & (self.h_end[lo:hi] > start)

@@ -119,6 +119,17 @@ int coral_time_cigar_scan(const coral_records_t *rec, int32_t min_gap, int32_t m
                           int32_t *gaps, uint32_t *gap_count, uint32_t gap_cap, int32_t iters,
                           float *ms_per_launch, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * coral_cluster_first_fit — HOST function (no device work).
+ *
+ * Greedy first-fit clustering of one (chr1, chr2, o1, o2) group of breakpoint candidates, exactly as
+ * /root/reference/src/breakpoint_utilities.py:268-282: candidate i joins the FIRST existing cluster that
+ * has any member with |p1 - p1'| < cutoff and |p2 - p2'| < cutoff, else opens a new cluster.
+ * cluster_of[i] receives the cluster ordinal (creation order), *n_clusters the number of clusters.
+ * ------------------------------------------------------------------------------------------------ */
+int coral_cluster_first_fit(int64_t n, const int64_t *p1, const int64_t *p2, int64_t cutoff,
+                            int32_t *cluster_of, int32_t *n_clusters);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,181 @@
+"""Shared checker: run the PRODUCT graph builder phase by phase and compare with the reference's golden snapshots."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from coral_amd import synth
+from tests.canon import canon, graph_snapshot, records_digest, strip_cn
+
+HASHSEED0 = os.environ.get("PYTHONHASHSEED") == "0"
+_cache = {}
+
+
+def load_case(golden_dir, case):
+    with open(os.path.join(golden_dir, "e2e_%s.json" % case)) as fp:
+        gold = json.load(fp)
+    name = gold["config"]
+    if name not in _cache:
+        cfg = synth.named_config(name)
+        rec = synth.generate(cfg, "cpu")
+        _cache[name] = (cfg, rec)
+    cfg, rec = _cache[name]
+    assert records_digest(rec) == gold["records_sha256"], "synthetic inputs changed: regenerate the goldens"
+    return gold, cfg, rec
+
+
+def cn_close(a, b, tol=1e-6):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert abs(x - y) <= tol * max(1.0, abs(y)), (x, y)
+
+
+def compare_graph_text(a, b):
+    """Every column byte-identical except the %f CN column: 1e-6 relative (north_star tolerance for CN floats)."""
+    la, lb = a.splitlines(), b.splitlines()
+    assert len(la) == len(lb)
+    for x, y in zip(la, lb):
+        fx, fy = x.split("\t"), y.split("\t")
+        assert len(fx) == len(fy)
+        if fx[0] == "sequence":
+            assert fx[:3] == fy[:3] and fx[4:] == fy[4:], (x, y)
+            assert abs(float(fx[3]) - float(fy[3])) <= 1e-6 * max(1.0, abs(float(fy[3]))) + 1e-6
+        elif fx[0] in ("concordant", "discordant", "source"):
+            assert fx[:2] == fy[:2] and fx[3:] == fy[3:], (x, y)
+            assert abs(float(fx[2]) - float(fy[2])) <= 1e-6 * max(1.0, abs(float(fy[2]))) + 1e-6
+        else:
+            assert x == y
+
+
+def check_product_against_golden(case, golden_dir, tmp_path, device):
+    """Phase-by-phase equality with the reference (strict order checks need PYTHONHASHSEED=0)."""
+    from coral_amd import infer_breakpoint_graph as ibg
+    from coral_amd.breakpoint_graph import breakpoint_info_text, compute_cn_lr, graph_text
+    from coral_amd.records import DeviceRecords
+    gold, cfg, rec = load_case(golden_dir, case)
+    cn = str(tmp_path / "cn.bed"); seeds = str(tmp_path / "seeds.bed")
+    synth.write_cn_bed(cfg, cn); synth.write_seed_bed(cfg, seeds)
+    dr = DeviceRecords(rec, device)
+    b = ibg.bam_to_breakpoint_nanopore(None, seeds, records=dr)
+    b.min_bp_cov_factor = gold["min_bp_support"]
+    b.read_cns(cn)
+    assert b.normal_cov == gold["A2"]["normal_cov"]
+    assert b.min_cluster_cutoff == gold["A2"]["min_cluster_cutoff"]
+    b.fetch()
+    assert len(b.read_length) == gold["A3"]["n_read_length"]
+    assert canon(dict(b.chimeric_alignments.items())) == gold["A3"]["chimeric_alignments"]
+    assert canon(b.nm_stats) == gold["A3"]["nm_stats"]
+    b.hash_alignment_to_seg()
+    assert canon(dict(b.chimeric_alignments.items())) == gold["A4"]["chimeric_alignments"]
+    # inverted index: chromosome key order and every per-segment read list must match; the order in which the
+    # CN-segment keys were first inserted is not observable (the reference only ever looks keys up)
+    def seg_norm(c):
+        return [[k, sorted(v["__dict__"], key=lambda kv: kv[0])] for k, v in c["__dict__"]]
+    assert seg_norm(canon(b.chimeric_alignments_seg.as_dict())) == seg_norm(gold["A4"]["chimeric_alignments_seg"])
+    b.find_amplicon_intervals()
+    if HASHSEED0:
+        assert canon(b.amplicon_intervals) == gold["A5"]["amplicon_intervals"]
+        assert canon(b.new_bp_list) == gold["A5"]["new_bp_list"]
+        assert canon(b.amplicon_interval_connections) == gold["A5"]["amplicon_interval_connections"]
+        assert canon(b.new_bp_stats) == gold["A5"]["new_bp_stats"]
+    else:
+        assert sorted(map(json.dumps, canon(b.amplicon_intervals))) == sorted(map(json.dumps, gold["A5"]["amplicon_intervals"]))
+    b.find_smalldel_breakpoints()
+    assert canon(b.large_indel_alignments) == gold["A6"]["large_indel_alignments"]
+    if HASHSEED0:
+        assert canon(b.new_bp_list) == gold["A6"]["new_bp_list"]
+    b.find_breakpoints()
+    if HASHSEED0:
+        assert canon(b.new_bp_list) == gold["A7"]["new_bp_list"]
+        assert canon(b.new_bp_stats) == gold["A7"]["new_bp_stats"]
+        assert canon(b.new_bp_ccids) == gold["A7"]["new_bp_ccids"]
+        assert canon(b.amplicon_interval_connections) == gold["A7"]["amplicon_interval_connections"]
+    b.build_graph()
+    if HASHSEED0:
+        assert canon(b.ccid2id) == gold["A9"]["ccid2id"]
+        assert [graph_snapshot(g) for g in b.lr_graph] == gold["A9"]["graphs"]
+    if "A10" not in gold:      # --output_bp variant
+        files = {}
+        for gi, g in enumerate(b.lr_graph):
+            stats = []
+            for e in g.discordant_edges:
+                for k, bp in enumerate(b.new_bp_list):
+                    if e[:6] == bp[:6]:
+                        stats.append(b.new_bp_stats[k]); break
+            files["out_amplicon%d_breakpoints.txt" % (gi + 1)] = breakpoint_info_text(g, stats)
+        if HASHSEED0:
+            assert files == gold["files"]
+        return b
+    b.assign_cov()
+    if HASHSEED0:
+        assert [graph_snapshot(g) for g in b.lr_graph] == gold["A10"]["graphs"]
+    for g in b.lr_graph:
+        compute_cn_lr(g, b.normal_cov)
+    if HASHSEED0:
+        for g, gg in zip(b.lr_graph, gold["A11"]["graphs"]):
+            s, cns = strip_cn(graph_snapshot(g))
+            sg, cng = strip_cn(gg)
+            assert s == sg
+            cn_close(cns, cng)
+        files = {"out_amplicon%d_graph.txt" % (gi + 1): graph_text(g) for gi, g in enumerate(b.lr_graph)}
+        assert sorted(files) == sorted(gold["files"])
+        for k in files:
+            compare_graph_text(files[k], gold["files"][k])
+    else:
+        got = sorted(l.split("\t")[0:3:2] for g in b.lr_graph for l in graph_text(g).splitlines() if l.startswith("disc"))
+        exp = sorted(l.split("\t")[0:3:2] for t in gold["files"].values() for l in t.splitlines() if l.startswith("disc"))
+        assert len(got) == len(exp)
+    return b
+
+
+# ---- oracle-backed stand-ins for the three device kernels (CPU tests of the host logic only) ----------------
+def install_cpu_kernel_fakes(monkeypatch):
+    from coral_amd import kernels
+    from oracle.hostrecords import HostRecords
+    hosts = {}
+
+    def host_of(dr):
+        if id(dr) not in hosts:
+            hosts[id(dr)] = HostRecords(dr._rec)
+        return hosts[id(dr)]
+
+    # The stand-ins replace only the LOCAL launches (records [dr.lo, dr.hi) of this process); the exchange and
+    # ordering code of coral_amd.kernels / coral_amd.sharding stays the product's own.
+    def scan_local(dr, min_gap, min_mapq, gap_cap):
+        h = host_of(dr)
+        mb, qi, b0, b1, rows = [], [], [], [], []
+        for i in range(dr.lo, dr.hi):
+            bl = h.blocks(i)
+            mb.append(sum(e - s for s, e in bl)); qi.append(h.infer_read_length(i) or 0)
+            b0.append(bl[0][0] if bl else -1); b1.append(bl[-1][1] if bl else -1)
+            if h.mapq[i] >= min_mapq:
+                for k in range(len(bl) - 1):
+                    if abs(bl[k + 1][0] - bl[k][1]) > min_gap:
+                        rows.append((i - dr.lo, k + 1, bl[k][1], bl[k + 1][0], b0[-1], b1[-1]))
+        t = lambda x: torch.tensor(x, dtype=torch.int32)
+        return t(mb), t(qi), t(b0), t(b1), torch.tensor(rows, dtype=torch.int64).reshape(-1, 6)
+
+    def coverage_local(dr, scan, sg):
+        h = host_of(dr)
+        out = torch.zeros((2, len(sg)), dtype=torch.int64)
+        for j, (t, s, e) in enumerate(sg):
+            idx = [i for i in h.region(h.chroms[t], s, e) if dr.lo <= i < dr.hi]
+            out[0, j] = sum(1 for i in idx if h.infer_read_length(i))
+            tot = 0
+            for i in idx:
+                if h.has_seq[i] and h.n_cigar[i]:
+                    tot += sum(max(0, min(b, e) - max(a, s)) for a, b in h.blocks(i))
+            out[1, j] = tot
+        return out
+
+    def points_local(dr, uniq, pair_cap):
+        h = host_of(dr)
+        keys = []
+        for j, (t, p) in enumerate(uniq):
+            keys += [(j << 32) | (int(i) - dr.lo) for i in h.region(h.chroms[t], p, p + 1) if dr.lo <= i < dr.hi]
+        return torch.tensor(keys, dtype=torch.int64)
+
+    monkeypatch.setattr(kernels, "_scan_local", scan_local)
+    monkeypatch.setattr(kernels, "_coverage_local", coverage_local)
+    monkeypatch.setattr(kernels, "_points_local", points_local)

@@ -1,0 +1,95 @@
+"""GPU parity of the whole hot path through the C ABI: golden fixtures, the CPU oracle on a larger seeded input,
+and size-independent properties at a size the oracle cannot finish quickly."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from coral_amd import synth
+from tests.product_check import HASHSEED0, check_product_against_golden
+
+pytestmark = pytest.mark.gpu
+CASES = ["tiny", "tiny_output_bp", "tiny_min_bp_support_30p0", "small", "ultra"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_gpu_matches_reference_golden(case, golden_dir, tmp_path):
+    b = check_product_against_golden(case, golden_dir, tmp_path, "cuda:0")
+    assert b.rec.device.type == "cuda"
+
+
+@pytest.mark.skipif(HASHSEED0, reason="already running with PYTHONHASHSEED=0")
+def test_strict_order_in_seeded_subprocess():
+    """Byte-identical discordant-edge order needs PYTHONHASHSEED=0 (Appendix A Q21): one child process."""
+    env = dict(os.environ, PYTHONHASHSEED="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-p",
+                        "no:cacheprovider", "-k", "golden"], env=env, capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+
+
+def test_gpu_matches_oracle_cfg1_subsample(tmp_path):
+    """Product (HIP kernels) vs CPU oracle on 12k reads of config 1: every line of every graph file; CN to 1e-6."""
+    from coral_amd import infer_breakpoint_graph as ibg
+    from coral_amd.breakpoint_graph import graph_text
+    from coral_amd.records import DeviceRecords
+    from oracle import coral_oracle as O
+    from oracle.hostrecords import HostRecords
+    from tests.product_check import compare_graph_text
+    cfg = synth.scaled_config("cfg1", 12000)
+    rec = synth.generate(cfg, "cpu")
+    cn = str(tmp_path / "cn.bed"); seeds = str(tmp_path / "seeds.bed")
+    synth.write_cn_bed(cfg, cn); synth.write_seed_bed(cfg, seeds)
+    b = ibg.build_graph_from_records(DeviceRecords(rec, "cuda:0"), seeds, cn, str(tmp_path / "gpu"))
+    ob, ofiles = O.reconstruct_graph(HostRecords(rec), seeds, cn)
+    assert len(b.lr_graph) == len(ob.lr_graph) and len(b.lr_graph) >= 1
+    assert b.normal_cov == ob.normal_cov
+    for g, og in zip(b.lr_graph, ob.lr_graph):
+        assert [e[:8] for e in g.sequence_edges] == [e[:8] for e in og.sequence_edges]
+        assert [e[8] for e in g.concordant_edges] == [e[8] for e in og.concordant_edges]
+        assert sorted(map(str, (e[:6] + [e[9]] for e in g.discordant_edges))) == \
+            sorted(map(str, (e[:6] + [e[9]] for e in og.discordant_edges)))
+        if HASHSEED0:
+            compare_graph_text(graph_text(g), O.graph_text(og))
+    for k in range(len(b.lr_graph)):
+        assert os.path.exists(str(tmp_path / ("gpu_amplicon%d_graph.txt" % (k + 1))))
+
+
+def test_properties_at_scale():
+    """Size-independent checks on 60k reads x 20 kb (≈ 1.2e8 CIGAR ops) generated on the GPU."""
+    import torch
+    from coral_amd import kernels
+    from coral_amd.records import DeviceRecords
+    cfg = synth.scaled_config("cfg3", 60000)
+    rec = synth.generate(cfg, "cuda:0", chunk_pieces=100000)
+    dr = DeviceRecords(rec, "cuda:0")
+    sc = kernels.cigar_scan(dr)
+    # (1) reference length implied by the CIGAR equals end - pos; aligned bases never exceed it
+    mb = sc.mbases.cpu().numpy().astype(np.int64)
+    span = (dr.h_end - dr.h_pos).astype(np.int64)
+    assert (mb <= span).all() and (mb > 0).all()
+    assert (sc.blk_first.cpu().numpy() >= dr.h_pos).all() and (sc.blk_last.cpu().numpy() <= dr.h_end).all()
+    # (2) coverage is additive: a tiling of a window sums to the coverage of the window (checksum of checksums)
+    t, ws, we = cfg.windows[1]
+    cuts = np.unique(np.concatenate([[ws, we], np.random.default_rng(1).integers(ws, we, 200)]))
+    tiles = [(t, int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:])]
+    nr, nb = kernels.segment_coverage(dr, sc, tiles + [(t, ws, we)])
+    assert nb[:-1].sum() == nb[-1]
+    # (3) whole-contig segment: bases == Σ mbases of records with SEQ on that contig (minus non-ACGT)
+    on = (dr.h_tid == t) & dr.h_has_seq
+    nonacgt = int((dr.h_tid[dr.h_nonacgt_rec] == t).sum())
+    nr2, nb2 = kernels.segment_coverage(dr, sc, [(t, 0, 1 << 30)])
+    assert nb2[0] == int(mb[on].sum()) - nonacgt and nr2[0] == int((dr.h_tid == t).sum())
+    # (4) point cover agrees with a record-level count on the host
+    pts = [(t, int(p)) for p in cuts[1:-1:7]]
+    cov = kernels.point_cover(dr, pts)
+    for (tt, p), c in zip(pts, cov):
+        assert len(c) == int(((dr.h_tid == tt) & (dr.h_pos <= p) & (dr.h_end > p)).sum())
+    # (5) every gap row is a real D/N run > 600 between two aligned blocks of a MAPQ >= 20 record
+    g = sc.gaps
+    assert len(g) > 0 and (g[:, 3] - g[:, 2] > 600).all() and (dr.h_mapq[g[:, 0]] >= 20).all()
+    # (6) idempotence: a second scan gives identical results
+    sc2 = kernels.cigar_scan(dr)
+    assert torch.equal(sc.mbases, sc2.mbases) and np.array_equal(sc.gaps, sc2.gaps)

@@ -58,6 +58,9 @@ def test_cigar_scan(case):
                 if abs(bl[k + 1][0] - bl[k][1]) > 600:
                     gaps.append((i, bl[k][1], bl[k + 1][0]))
     got = [(int(g[0]), int(g[2]), int(g[3])) for g in res.gaps]
+    for g in res.gaps:
+        bl = host.blocks(int(g[0]))
+        assert (int(g[4]), int(g[5])) == (bl[0][0], bl[-1][1])
     assert got == gaps, name
     if name == "odd":
         assert len(gaps) == 5     # a, b(N), e, i x2

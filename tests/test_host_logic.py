@@ -1,0 +1,27 @@
+"""Host logic of the product (SA parsing, candidates, clustering, interval BFS, graph assembly, CN, writers) vs the
+reference's golden snapshots, on the CPU: the three device kernels are replaced by oracle-backed stand-ins here
+(tests only — the product itself has no CPU path; the real kernels are checked by the -m gpu tests)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.product_check import HASHSEED0, check_product_against_golden, install_cpu_kernel_fakes
+
+CASES = ["tiny", "tiny_output_bp", "tiny_min_bp_support_30p0", "small", "ultra"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_host_logic_matches_reference(case, golden_dir, tmp_path, monkeypatch):
+    install_cpu_kernel_fakes(monkeypatch)
+    check_product_against_golden(case, golden_dir, tmp_path, "cpu")
+
+
+@pytest.mark.skipif(HASHSEED0, reason="already running with PYTHONHASHSEED=0")
+def test_strict_order_in_seeded_subprocess():
+    env = dict(os.environ, PYTHONHASHSEED="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]

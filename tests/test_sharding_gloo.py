@@ -1,0 +1,45 @@
+"""N > 1 path on CPU: two gloo ranks, records split in two, exchange = all-gather-v of candidate rows + all-reduce
+of the per-segment sums.  The merged result must equal the reference golden (== the unsharded result)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from tests.product_check import compare_graph_text
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("case", ["tiny", "small"])
+def test_two_rank_shard_merge_equals_reference(case, golden_dir, tmp_path):
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, PYTHONHASHSEED="0", RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_shard_worker.py"), case, str(tmp_path)],
+                                      env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    with open(os.path.join(golden_dir, "e2e_%s.json" % case)) as fp:
+        gold = json.load(fp)
+    with open(tmp_path / "result.json") as fp:
+        res = json.load(fp)
+    assert res["normal_cov"] == gold["A2"]["normal_cov"]
+    assert 0 < res["shard"][1] < res["shard"][2]
+    assert sorted(res["files"]) == sorted(gold["files"])
+    for k in res["files"]:
+        compare_graph_text(res["files"][k], gold["files"][k])
+        assert open(str(tmp_path / ("sh" + k[3:]))).read() == res["files"][k]
