@@ -44,6 +44,13 @@ def lib():
     L.coral_read_counter.argtypes = [P, C.POINTER(C.c_uint32), P]
     L.coral_cluster_first_fit.argtypes = [C.c_int64, P, P, C.c_int64, P, C.POINTER(C.c_int32)]
     L.coral_cluster_first_fit.restype = C.c_int
+    L.coral_bam_decode_open.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]
+    L.coral_bam_decode_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.coral_bam_decode_fill.argtypes = [C.c_void_p] + [P] * 20
+    L.coral_bam_decode_close.argtypes = [C.c_void_p]
+    L.coral_bam_last_error.restype = C.c_char_p
+    for name in ("coral_bam_decode_open", "coral_bam_decode_sizes", "coral_bam_decode_fill", "coral_bam_decode_close"):
+        getattr(L, name).restype = C.c_int
     for name in ("coral_cigar_scan", "coral_time_cigar_scan", "coral_segment_coverage", "coral_point_cover",
                  "coral_read_counter"):
         getattr(L, name).restype = C.c_int

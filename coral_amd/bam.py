@@ -1,0 +1,147 @@
+"""BAM input/output for the graph-build path.
+
+``decode_bam`` is the product path: the native multi-threaded BGZF/BAM decoder of libcoral_hip.so
+(csrc/coral_bam.cpp) turns the file into the SoA ``Records`` the kernels consume — the BAM is read once.
+``write_bam`` is a small pure-Python BAM writer used by tests and tools to materialise synthetic records as a
+real coordinate-sorted BAM (htslib / pysam are not available offline); it is not on the hot path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import struct
+import zlib
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .synth import Records, hash_u32, S_SEQ, sa_entry_string
+
+
+def decode_bam(path: str, n_threads: Optional[int] = None) -> Records:
+    L = _lib.lib()
+    if n_threads is None:
+        n_threads = max(1, min(16, os.cpu_count() or 1))
+    h = C.c_void_p()
+    rc = L.coral_bam_decode_open(path.encode(), n_threads, C.byref(h))
+    if rc != 0:
+        raise _lib.CoralHipError("coral_bam_decode_open(%s) failed (%d): %s" % (path, rc, L.coral_bam_last_error().decode()))
+    try:
+        sz = (C.c_int64 * 8)()
+        _lib.check(L.coral_bam_decode_sizes(h, sz), "coral_bam_decode_sizes")
+        n, ncig, nsa, nna, nnames, nbytes, nref, rbytes = (int(v) for v in sz)
+        i32 = lambda k: np.empty(max(k, 0), dtype=np.int32)
+        tid, pos, end, flag, mapq, qlen, has_seq, nm, name_id, n_cigar = (i32(n) for _ in range(10))
+        cigar_off = np.empty(n + 1, dtype=np.int64)
+        cigar = np.empty(ncig, dtype=np.uint32)
+        sa_off = np.empty(n + 1, dtype=np.int64)
+        sa = np.empty((nsa, 8), dtype=np.int32)
+        sa_nm = i32(nsa)
+        na_rec = np.empty(nna, dtype=np.int64)
+        na_pos = i32(nna)
+        names_buf = C.create_string_buffer(max(nbytes, 1))
+        ref_buf = C.create_string_buffer(max(rbytes, 1))
+        ref_lens = i32(nref)
+        ptr = lambda a: a.ctypes.data
+        _lib.check(L.coral_bam_decode_fill(h, ptr(tid), ptr(pos), ptr(end), ptr(flag), ptr(mapq), ptr(qlen), ptr(has_seq),
+                                           ptr(nm), ptr(name_id), ptr(n_cigar), ptr(cigar_off), ptr(cigar), ptr(sa_off),
+                                           ptr(sa), ptr(sa_nm), ptr(na_rec), ptr(na_pos), C.addressof(names_buf),
+                                           C.addressof(ref_buf), ptr(ref_lens)), "coral_bam_decode_fill")
+    finally:
+        L.coral_bam_decode_close(h)
+    names = names_buf.raw[:nbytes].split(b"\0")[:nnames]
+    refs = ref_buf.raw[:rbytes].split(b"\0")[:nref]
+    t = torch.from_numpy
+    return Records(n=n, tid=t(tid), pos=t(pos), end=t(end), flag=t(flag), mapq=t(mapq), qlen=t(qlen), has_seq=t(has_seq),
+                   nm=t(nm), name_id=t(name_id), n_cigar=t(n_cigar), cigar_off=t(cigar_off),
+                   cigar=t(cigar.view(np.int32)), sa_off=t(sa_off), sa=t(sa), sa_nm=t(sa_nm), nonacgt_rec=t(na_rec),
+                   nonacgt_pos=t(na_pos), n_names=nnames, name_gid=None, names=[x.decode() for x in names],
+                   header_chroms=[x.decode() for x in refs], header_lens=[int(x) for x in ref_lens])
+
+
+# ----------------------------------------------------------------------------------------------
+# pure-Python writer (tests / tools)
+# ----------------------------------------------------------------------------------------------
+_SEQ_CODE = {65: 1, 67: 2, 71: 4, 84: 8, 78: 15}     # A C G T N
+
+
+def _reg2bin(beg: int, end: int) -> int:
+    end -= 1
+    for shift, off in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return off + (beg >> shift)
+    return 0
+
+
+def _bgzf_blocks(data: bytes, level: int = 1):
+    for i in range(0, len(data), 0xff00):
+        chunk = data[i:i + 0xff00]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = co.compress(chunk) + co.flush()
+        bsize = len(comp) + 25
+        yield (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + comp +
+               struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+    yield bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")      # BGZF EOF marker
+
+
+def write_bam(rec: Records, path: str, seed: int = 0, long_cigar_as_cg: bool = True) -> None:
+    """Serialise ``rec`` as a coordinate-sorted BAM (SEQ = deterministic ACGT with N at the listed non-ACGT
+    positions, QUAL absent, tags NM:i and SA:Z; CIGARs with more than 65535 ops go to the CG:B,I tag)."""
+    g = lambda x: x.cpu().numpy()
+    tid, pos, flag, mapq, qlen, has_seq, nm, name_id, n_cigar = (g(getattr(rec, k)) for k in
+                                                                ("tid", "pos", "flag", "mapq", "qlen", "has_seq", "nm", "name_id", "n_cigar"))
+    cigar_off, cigar = g(rec.cigar_off), g(rec.cigar).view(np.uint32)
+    sa_off, sa, sa_nm = g(rec.sa_off), g(rec.sa), g(rec.sa_nm)
+    names = rec.materialise_names()
+    na = {}
+    for r, p in zip(g(rec.nonacgt_rec), g(rec.nonacgt_pos)):
+        na.setdefault(int(r), []).append(int(p))
+    out = bytearray()
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (c, l) for c, l in zip(rec.header_chroms, rec.header_lens))
+    out += b"BAM\x01" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(rec.header_chroms))
+    for c, l in zip(rec.header_chroms, rec.header_lens):
+        out += struct.pack("<i", len(c) + 1) + c.encode() + b"\0" + struct.pack("<i", l)
+    lut = np.zeros(256, dtype=np.uint8)
+    for k, v in _SEQ_CODE.items():
+        lut[k] = v
+    ref_adv = np.array([1, 0, 1, 1, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0])
+    qry_adv = np.array([1, 1, 0, 0, 1, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0])
+    for i in range(rec.n):
+        ops = cigar[cigar_off[i]: cigar_off[i] + n_cigar[i]]
+        l_seq = int(qlen[i]) if has_seq[i] else 0
+        seq_bytes = b""
+        if l_seq:
+            k = torch.arange(l_seq, dtype=torch.int64) + i * (1 << 22)
+            s = np.frombuffer(b"ACGT", dtype=np.uint8)[(hash_u32(seed, S_SEQ, k) & 3).numpy()].copy()
+            if i in na:     # reference position -> query offset through the CIGAR
+                op, ln = ops & 15, (ops >> 4).astype(np.int64)
+                r0 = int(pos[i]) + np.cumsum(ref_adv[op] * ln) - ref_adv[op] * ln
+                q0 = np.cumsum(qry_adv[op] * ln) - qry_adv[op] * ln
+                for p in na[i]:
+                    j = np.nonzero((ref_adv[op] * qry_adv[op] == 1) & (r0 <= p) & (p < r0 + ln))[0][0]
+                    s[q0[j] + (p - r0[j])] = 78
+            code = lut[s]
+            if l_seq & 1:
+                code = np.append(code, 0)
+            seq_bytes = ((code[0::2] << 4) | code[1::2]).astype(np.uint8).tobytes()
+        tags = b"NMi" + struct.pack("<i", int(nm[i]))
+        if i in getattr(rec, "sa_text", {}):            # tests: verbatim SA text (odd CIGAR shapes)
+            tags += b"SAZ" + rec.sa_text[i].encode() + b"\0"
+        elif sa_off[i + 1] > sa_off[i]:
+            ents = [sa_entry_string(sa[j], int(sa_nm[j]), rec.header_chroms) for j in range(sa_off[i], sa_off[i + 1])]
+            tags += b"SAZ" + (";".join(ents) + ";").encode() + b"\0"
+        rlen = int((ref_adv[ops & 15] * (ops >> 4)).sum()) if not (flag[i] & 4) else 0
+        cig_field = ops
+        if long_cigar_as_cg and len(ops) > 65535:
+            tags += b"CGBI" + struct.pack("<I", len(ops)) + ops.astype("<u4").tobytes()
+            cig_field = np.array([(l_seq << 4) | 4, (rlen << 4) | 3], dtype=np.uint32)
+        name = names[name_id[i]].encode() + b"\0"
+        body = struct.pack("<iiBBHHHiiii", int(tid[i]), int(pos[i]), len(name), int(mapq[i]),
+                           _reg2bin(int(pos[i]), int(pos[i]) + max(1, rlen)), len(cig_field), int(flag[i]), l_seq, -1, -1, 0)
+        body += name + cig_field.astype("<u4").tobytes() + seq_bytes + b"\xff" * l_seq + tags
+        out += struct.pack("<i", len(body)) + body
+    with open(path, "wb") as fp:
+        for blk in _bgzf_blocks(bytes(out)):
+            fp.write(blk)

@@ -135,17 +135,36 @@ def cn_problem(g, normal_cov):
     return w_inv, w_lin, w_log, A
 
 
-def solve_cn_lr(w_inv, w_lin, w_log, A, tol=1e-13, max_iter=500):
+def _independent_rows(A, tol=1e-9):
+    """Indices of a maximal linearly independent subset of the rows of A (entries are 0 / ±1), by modified
+    Gram-Schmidt.  Redundant balance rows are consistent (right-hand side 0), so dropping them changes nothing."""
+    keep, basis = [], []
+    for k in range(A.shape[0]):
+        v = A[k].astype(np.float64).copy()
+        for b in basis:
+            v -= (v @ b) * b
+        nv = np.linalg.norm(v)
+        if nv > tol * max(1.0, np.linalg.norm(A[k])):
+            basis.append(v / nv)
+            keep.append(k)
+    return keep
+
+
+def solve_cn_lr(w_inv, w_lin, w_log, A, max_iter=200):
     """argmin  Σ w_inv/x + w_lin·x − w_log·log x   s.t.  A x = 0,  x > 0,   started at x = 1 (bg:546-548).
 
-    Infeasible-start Newton on the full KKT system [[H, Aᵀ], [A, 0]] (H diagonal, possibly with zero
-    entries for concordant edges without read support; A possibly rank deficient -> least squares), with
-    a backtracking search on the KKT residual that keeps x strictly positive.  float64 throughout.
+    Infeasible-start Newton on the KKT system [[H, Aᵀ], [A, 0]] (H diagonal, possibly with zero entries for
+    concordant edges without read support, so no Schur complement), with a backtracking search on the KKT
+    residual that keeps x strictly positive.  Iterates until the Newton step is below 1e-13 relative (or the
+    residual can no longer be reduced in float64).  Linearly dependent balance rows are removed first so the KKT
+    matrix is non-singular and a plain LU solve can be used.
     """
-    n, p = len(w_lin), A.shape[0]
+    n = len(w_lin)
+    if A.shape[0]:
+        A = A[_independent_rows(A)]
+    p = A.shape[0]
     x = np.ones(n)
     nu = np.zeros(p)
-    scale = max(1.0, float(np.max(np.abs(w_lin)))) if n else 1.0
     K = np.zeros((n + p, n + p))
     K[:n, n:] = A.T
     K[n:, :n] = A
@@ -157,25 +176,32 @@ def solve_cn_lr(w_inv, w_lin, w_log, A, tol=1e-13, max_iter=500):
     r = kkt_residual(x, nu)
     for _ in range(max_iter):
         K[diag, diag] = w_log / (x * x) + 2.0 * w_inv / (x * x * x)
-        step = np.linalg.lstsq(K, -r, rcond=None)[0]
+        try:
+            step = np.linalg.solve(K, -r)
+        except np.linalg.LinAlgError:
+            step = np.linalg.lstsq(K, -r, rcond=None)[0]
         dx, dnu = step[:n], step[n:]
         t = 1.0
         shrink = dx < 0
         if shrink.any():
             t = min(1.0, 0.99 * float(np.min(-x[shrink] / dx[shrink])))
         r0 = np.linalg.norm(r)
-        while t > 1e-14:
+        improved = False
+        while t > 1e-10:
             r_new = kkt_residual(x + t * dx, nu + t * dnu)
             if np.linalg.norm(r_new) <= (1.0 - 0.01 * t) * r0:
+                improved = True
                 break
             t *= 0.5
-        else:
-            r_new = kkt_residual(x + t * dx, nu + t * dnu)
+        small = float(np.max(np.abs(dx) / x)) < 1e-13
+        if not improved:
+            if small:                       # at the float64 floor: take the (tiny) full step and stop
+                x = x + dx
+            break
         x = x + t * dx
         nu = nu + t * dnu
         r = r_new
-        if np.max(np.abs(r[:n])) <= tol * scale and (p == 0 or np.max(np.abs(r[n:])) <= tol * max(1.0, float(np.max(x)))) \
-                and np.max(np.abs(t * dx) / x) < 1e-13:
+        if small:
             break
     return x
 

@@ -130,6 +130,28 @@ int coral_time_cigar_scan(const coral_records_t *rec, int32_t min_gap, int32_t m
 int coral_cluster_first_fit(int64_t n, const int64_t *p1, const int64_t *p2, int64_t cutoff,
                             int32_t *cluster_of, int32_t *n_clusters);
 
+/* ------------------------------------------------------------------------------------------------
+ * coral_bam_decode_* — HOST functions: BAM/BGZF file -> structure-of-arrays records, decoded ONCE.
+ *
+ * Replaces pysam.AlignmentFile(path, 'rb') + the whole-file fetch() loop
+ * (/root/reference/src/infer_breakpoint_graph.py:65, :140-158).  `open` inflates (n_threads zlib workers) and
+ * parses the whole file; `sizes` reports {n_rec, n_cigar_words (padded), n_sa_rows, n_nonacgt, n_names,
+ * names_bytes, n_ref, ref_names_bytes}; `fill` copies everything into caller-allocated arrays (names and
+ * reference names as consecutive NUL-terminated strings); `close` frees the handle.
+ * SA rows are 8 ints: ref id, 1-based pos, strand (0 '+', 1 '-'), leading S, M, +I/-D, trailing S, mapq
+ * (leading S = -2 marks a CIGAR that contains S and M but is not one of the nine shapes of
+ * cigar_parsing.py:219-229).  qlen is l_seq, or the CIGAR-implied query length when SEQ is '*'.
+ * ------------------------------------------------------------------------------------------------ */
+int coral_bam_decode_open(const char *path, int32_t n_threads, void **handle);
+int coral_bam_decode_sizes(void *handle, int64_t sizes[8]);
+int coral_bam_decode_fill(void *handle, int32_t *tid, int32_t *pos, int32_t *end, int32_t *flag, int32_t *mapq,
+                          int32_t *qlen, int32_t *has_seq, int32_t *nm, int32_t *name_id, int32_t *n_cigar,
+                          int64_t *cigar_off, uint32_t *cigar, int64_t *sa_off, int32_t *sa, int32_t *sa_nm,
+                          int64_t *nonacgt_rec, int32_t *nonacgt_pos, char *names, char *ref_names,
+                          int32_t *ref_lens);
+int coral_bam_decode_close(void *handle);
+const char *coral_bam_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif
