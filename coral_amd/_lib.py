@@ -42,6 +42,8 @@ def lib():
     L.coral_segment_coverage.argtypes = [R, P, P, C.c_int32, P, P, P, P, P, P, P, P]
     L.coral_point_cover.argtypes = [R, C.c_int32, P, P, P, P, C.c_uint32, P]
     L.coral_read_counter.argtypes = [P, C.POINTER(C.c_uint32), P]
+    L.coral_set_scan_variant.argtypes = [C.c_int]
+    L.coral_set_scan_variant.restype = C.c_int
     L.coral_cluster_first_fit.argtypes = [C.c_int64, P, P, C.c_int64, P, C.POINTER(C.c_int32)]
     L.coral_cluster_first_fit.restype = C.c_int
     L.coral_bam_decode_open.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]

@@ -12,6 +12,7 @@
 #include "../../include/coral_hip.h"
 
 #define WAVE 64
+typedef uint32_t cquad_t __attribute__((ext_vector_type(4)));   // one 16-byte CIGAR quad = one dwordx4 load
 #define SCAN_BLOCK 256          // 4 waves per workgroup
 #define OP_PAD_QUAD 0x0000000Fu // op 15, length 0: consumes nothing
 
@@ -78,12 +79,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan(
     const long long wave = (long long)blockIdx.x * (SCAN_BLOCK / WAVE) + (threadIdx.x >> 6);
     const long long nwaves = (long long)gridDim.x * (SCAN_BLOCK / WAVE);
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const uint4 pad = make_uint4(OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD);
+    const cquad_t pad = {OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD};
 
     for (long long r = wave; r < n_rec; r += nwaves) {
         const int n = n_cigar[r];
         const int nq = (n + 3) >> 2;
-        const uint4 *__restrict__ q = reinterpret_cast<const uint4 *>(cigar + cigar_off[r]);
+        const cquad_t *__restrict__ q = reinterpret_cast<const cquad_t *>(cigar + cigar_off[r]);
         const int p0 = pos[r];
         const bool gaps_on = ((flagmq[r] >> 16) & 0xff) >= min_mapq;
 
@@ -91,10 +92,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan(
         int carry_end = 0;   // end (relative, >= 1) of the last aligned block seen so far; 0 = none
         int msum = 0, qsum = 0, first = 0x7fffffff;
 
-        uint4 cur = pad;
+        cquad_t cur = pad;
         if (lane < nq) cur = q[lane];
         for (int c = 0; c < nq; c += WAVE) {
-            uint4 nxt = pad;
+            cquad_t nxt = pad;
             if (c + WAVE + lane < nq) nxt = q[c + WAVE + lane];   // prefetch the next KiB
 
             const uint32_t v[4] = {cur.x, cur.y, cur.z, cur.w};
@@ -160,6 +161,223 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K1 (variant 2)  same contract as k_cigar_scan, restructured for the memory system:
+//   * the (record, chunk) sequence of a wave is flattened and the loads run TWO chunks (2 KiB per wave)
+//     ahead of the arithmetic, across record boundaries, so a wave never idles on the dependent
+//     metadata -> first-quad load chain at the start of a record;
+//   * record metadata is wave-uniform and fetched with scalar loads (readfirstlane'd record ordinal);
+//   * the wave scan / reductions use DPP row shifts + row broadcasts (6 VALU ops, no LDS crossbar), and
+//     wave-uniform values are taken with v_readlane instead of a shuffle.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_zero(int src) {
+    return __builtin_amdgcn_update_dpp(0, src, CTRL, ROW_MASK, 0xf, true);
+}
+
+__device__ __forceinline__ int wave_incl_scan_add_dpp(int x) {
+    x += dpp_zero<0x111, 0xf>(x);   // row_shr:1
+    x += dpp_zero<0x112, 0xf>(x);   // row_shr:2
+    x += dpp_zero<0x114, 0xf>(x);   // row_shr:4
+    x += dpp_zero<0x118, 0xf>(x);   // row_shr:8
+    x += dpp_zero<0x142, 0xa>(x);   // row_bcast:15 -> rows 1, 3
+    x += dpp_zero<0x143, 0xc>(x);   // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
+__device__ __forceinline__ int wave_sum_dpp(int x) {
+    return __builtin_amdgcn_readlane(wave_incl_scan_add_dpp(x), 63);
+}
+
+#define BATCH 4   // chunks (KiB) a wave loads back to back: 4 KiB per wave in flight while the previous 4 KiB are processed
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
+    long long n_rec, const int32_t *__restrict__ pos, const int32_t *__restrict__ flagmq,
+    const int32_t *__restrict__ n_cigar, const int64_t *__restrict__ cigar_off,
+    const uint32_t *__restrict__ cigar, int min_gap, int min_mapq, int32_t *__restrict__ mbases,
+    int32_t *__restrict__ qinfer, int32_t *__restrict__ blk_first, int32_t *__restrict__ blk_last,
+    int32_t *__restrict__ gaps, uint32_t *__restrict__ gap_count, uint32_t gap_cap) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (SCAN_BLOCK / WAVE) + (threadIdx.x >> 6)));
+    const long long nwaves = (long long)gridDim.x * (SCAN_BLOCK / WAVE);
+    const cquad_t pad = {OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD};
+    // per-op classes, 4 bits per BAM op code: bit0 advances the reference (M D N = X), bit1 aligned block (M = X),
+    // bit2 counts towards infer_read_length (M I S H = X); op 15 (padding) and the unused codes are 0.
+    const unsigned long long OPCLASS = 0x0000000770441147ull;
+
+    // fetch cursor: (record, first chunk of the batch); runs one batch ahead of the arithmetic, across records.
+    // Record metadata is wave-uniform (scalar loads) and requested ONE RECORD AHEAD of its use, so the wave never
+    // stalls on the metadata -> first-quad dependency when it moves to its next record.
+    long long fr = wave;
+    int fc = 0, fnq = 0;
+    const cquad_t *__restrict__ fq = reinterpret_cast<const cquad_t *>(cigar);
+    int f_nn = 0;            // n_cigar / cigar_off of record fr + nwaves (requested earlier)
+    long long f_noff = 0;
+    const long long last_rec = n_rec - 1;      // n_rec >= 1 (checked by the launcher)
+    auto f_request = [&](long long r) {        // unconditional scalar loads (clamped): no select on the loaded value
+        const long long rr = r < n_rec ? r : last_rec;
+        f_nn = n_cigar[rr];
+        f_noff = cigar_off[rr];
+    };
+    auto f_meta = [&]() {      // switch to record fr using the values requested earlier, request the one after
+        fc = 0;
+        fnq = fr < n_rec ? (f_nn + 3) >> 2 : 0;
+        fq = reinterpret_cast<const cquad_t *>(cigar + f_noff);
+        f_request(fr + nwaves);
+    };
+    auto f_fetch = [&](cquad_t (&dst)[BATCH]) {
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            dst[j] = pad;
+            if (fc + j * WAVE + lane < fnq) dst[j] = fq[fc + j * WAVE + lane];     // exec-masked dwordx4
+        }
+    };
+    auto f_step = [&]() {
+        fc += BATCH * WAVE;
+        if (fc >= fnq) {
+            fr += nwaves;
+            f_meta();
+        }
+    };
+    // process cursor (its metadata is requested one record ahead as well)
+    long long pr = wave;
+    int pc = 0, pnq = 0, p0 = 0;
+    bool gaps_on = false;
+    int p_nn = 0, p_npos = 0, p_nfm = 0;
+    auto p_request = [&](long long r) {
+        const long long rr = r < n_rec ? r : last_rec;
+        p_nn = n_cigar[rr];
+        p_npos = pos[rr];
+        p_nfm = flagmq[rr];
+    };
+    auto p_meta = [&]() {
+        pc = 0;
+        pnq = (p_nn + 3) >> 2;
+        p0 = p_npos;
+        gaps_on = ((p_nfm >> 16) & 0xff) >= min_mapq;
+        p_request(pr + nwaves);
+    };
+    f_request(fr);
+    p_request(pr);
+    f_meta();
+    p_meta();
+    cquad_t cur[BATCH], nxt[BATCH];
+    f_fetch(cur);
+    f_step();
+
+    int carry_ref = 0, carry_end = 0, msum = 0, qsum = 0, first = 0;
+    while (pr < n_rec) {
+        // Touch the current batch: the compiler places its wait for these registers HERE, i.e. before the next
+        // batch is issued, so the next 4 KiB stay in flight for the whole of this batch's arithmetic.
+        asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
+        f_fetch(nxt);
+        f_step();
+
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            if (j > 0 && pc + j * WAVE >= pnq) break;        // wave-uniform
+            const cquad_t b0 = cur[j];
+            // ---- branch-free decode of the lane's four ops
+            int len[4], adv[4], aend[4], ref[4];
+            bool aln[4];
+            int tot = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t w = b0[k];
+                const uint32_t f = (uint32_t)(OPCLASS >> ((w << 2) & 60u));
+                len[k] = (int)(w >> 4);
+                adv[k] = len[k] & -(int)(f & 1u);
+                const int alen = len[k] & -(int)((f >> 1) & 1u);
+                aln[k] = (f >> 1) & 1u;
+                aend[k] = alen;
+                msum += alen;
+                qsum += len[k] & -(int)((f >> 2) & 1u);
+                tot += adv[k];
+            }
+            const int incl = wave_incl_scan_add_dpp(tot);
+            ref[0] = carry_ref + incl - tot;
+            ref[1] = ref[0] + adv[0];
+            ref[2] = ref[1] + adv[1];
+            ref[3] = ref[2] + adv[2];
+            // running "end of the last aligned block" inside the lane (0 = none yet)
+            int run[4];
+            run[0] = aln[0] ? ref[0] + aend[0] : 0;
+            run[1] = aln[1] ? ref[1] + aend[1] : run[0];
+            run[2] = aln[2] ? ref[2] + aend[2] : run[1];
+            run[3] = aln[3] ? ref[3] + aend[3] : run[2];
+            // previous block end seen by this lane = max over earlier lanes (ends never decrease), else the carry
+            int mx = run[3];
+            mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x111, 0xf, 0xf, true));
+            mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x112, 0xf, 0xf, true));
+            mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x114, 0xf, 0xf, true));
+            mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x118, 0xf, 0xf, true));
+            mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x142, 0xa, 0xf, true));
+            mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x143, 0xc, 0xf, true));
+            const int shifted = __builtin_amdgcn_update_dpp(carry_end, mx, 0x138, 0xf, 0xf, false);   // wave_shr:1
+            const int prev_in = max(shifted, carry_end);
+            if (carry_end == 0) {                    // (wave-uniform) still looking for the record's first block
+                const unsigned long long has = __ballot(run[3] != 0);
+                if (has != 0ull) {
+                    int lf = ref[3];
+                    lf = aln[2] ? ref[2] : lf;
+                    lf = aln[1] ? ref[1] : lf;
+                    lf = aln[0] ? ref[0] : lf;
+                    first = __builtin_amdgcn_readlane(lf, (int)__builtin_ctzll(has));
+                }
+            }
+            // gap test, branch-free: distance from the previous block end (a huge "previous" when there is none)
+            const int none = 0x3fffffff;
+            const int pin = prev_in == 0 ? none : prev_in;
+            const int pv1 = run[0] ? run[0] : pin, pv2 = run[1] ? run[1] : pin, pv3 = run[2] ? run[2] : pin;
+            const bool h0 = aln[0] && (ref[0] - pin > min_gap);
+            const bool h1 = aln[1] && (ref[1] - pv1 > min_gap);
+            const bool h2 = aln[2] && (ref[2] - pv2 > min_gap);
+            const bool h3 = aln[3] && (ref[3] - pv3 > min_gap);
+            if (gaps_on && __ballot(h0 | h1 | h2 | h3) != 0ull) {          // rare: some lane holds a large gap
+                const int pv[4] = {pin, pv1, pv2, pv3};
+                const bool hit[4] = {h0, h1, h2, h3};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (hit[k]) {
+                        const uint32_t slot = atomicAdd(gap_count, 1u);
+                        if (slot < gap_cap) {
+                            int4 row = make_int4((int)pr, (pc + j * WAVE + lane) * 4 + k, p0 + pv[k], p0 + ref[k]);
+                            reinterpret_cast<int4 *>(gaps)[slot] = row;
+                        }
+                    }
+                }
+            }
+            carry_ref += __builtin_amdgcn_readlane(incl, 63);
+            carry_end = max(carry_end, __builtin_amdgcn_readlane(mx, 63));
+        }
+
+        if (pc + BATCH * WAVE >= pnq) {          // last batch of this record: write its summary, move on
+            const int ms = wave_sum_dpp(msum);
+            const int qs = wave_sum_dpp(qsum);
+            if (lane == 0) {
+                mbases[pr] = ms;
+                qinfer[pr] = qs;
+                blk_first[pr] = (carry_end > 0) ? p0 + first : -1;
+                blk_last[pr] = (carry_end > 0) ? p0 + carry_end : -1;
+            }
+            carry_ref = 0; carry_end = 0; msum = 0; qsum = 0; first = 0;
+            pr += nwaves;
+            p_meta();
+        } else {
+            pc += BATCH * WAVE;
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) cur[j] = nxt[j];
+    }
+}
+
+static int g_scan_variant = 2;
+extern "C" int coral_set_scan_variant(int v) {
+    if (v != 1 && v != 2) return CORAL_ERR_ARG;
+    g_scan_variant = v;
+    return CORAL_OK;
+}
+
 static int scan_grid(long long n_rec) {
     long long blocks = (n_rec + (SCAN_BLOCK / WAVE) - 1) / (SCAN_BLOCK / WAVE);
     const long long cap = 256 * 8;   // 256 CUs x 8 workgroups of 4 waves = 32 waves per CU
@@ -186,9 +404,14 @@ extern "C" int coral_cigar_scan(const coral_records_t *rec, int32_t min_gap, int
     if (!mbases || !qinfer || !blk_first || !blk_last || !gap_count || (gap_cap && !gaps))
         return set_err(CORAL_ERR_ARG, "cigar_scan: null output");
     if (((uintptr_t)gaps) & 15u) return set_err(CORAL_ERR_ARG, "cigar_scan: gaps must be 16-byte aligned");
-    hipLaunchKernelGGL(k_cigar_scan, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
-                       (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
-                       (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
+    if (g_scan_variant == 1)
+        hipLaunchKernelGGL(k_cigar_scan, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
+                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
+                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
+    else
+        hipLaunchKernelGGL(k_cigar_scan_v2, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
+                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
+                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_err(e, "cigar_scan launch");
     return CORAL_OK;
@@ -318,19 +541,19 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_seg_walk(
     const long long wave = (long long)blockIdx.x * (SCAN_BLOCK / WAVE) + (threadIdx.x >> 6);
     const long long nwaves = (long long)gridDim.x * (SCAN_BLOCK / WAVE);
     const long long n_strad = *strad_count;
-    const uint4 pad = make_uint4(OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD);
+    const cquad_t pad = {OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD};
     for (long long w = wave; w < n_strad; w += nwaves) {
         const long long r = strad[w];
         const int t = tid[r], p0 = pos[r], e0 = end[r];
         const int nq = (n_cigar[r] + 3) >> 2;
-        const uint4 *__restrict__ q = reinterpret_cast<const uint4 *>(cigar + cigar_off[r]);
+        const cquad_t *__restrict__ q = reinterpret_cast<const cquad_t *>(cigar + cigar_off[r]);
         int j = first_seg_ending_after(seg_tid, seg_end, n_seg, t, p0);
         for (; j < n_seg && seg_tid[j] == t && seg_start[j] < e0; ++j) {
             const int s = seg_start[j] - p0, e = seg_end[j] - p0;    // segment in record-relative coordinates
             long long acc = 0;
             int carry_ref = 0;
             for (int c = 0; c < nq && carry_ref < e; c += WAVE) {
-                uint4 cur = pad;
+                cquad_t cur = pad;
                 if (c + lane < nq) cur = q[c + lane];
                 const uint32_t v[4] = {cur.x, cur.y, cur.z, cur.w};
                 int len[4], adv[4];

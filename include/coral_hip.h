@@ -119,6 +119,9 @@ int coral_time_cigar_scan(const coral_records_t *rec, int32_t min_gap, int32_t m
                           int32_t *gaps, uint32_t *gap_count, uint32_t gap_cap, int32_t iters,
                           float *ms_per_launch, void *stream);
 
+/* Tuning hook for A/B measurements: 1 = first cigar_scan kernel, 2 = prefetching DPP variant (default). */
+int coral_set_scan_variant(int variant);
+
 /* ------------------------------------------------------------------------------------------------
  * coral_cluster_first_fit — HOST function (no device work).
  *
