@@ -44,6 +44,10 @@ def lib():
     L.coral_read_counter.argtypes = [P, C.POINTER(C.c_uint32), P]
     L.coral_set_scan_variant.argtypes = [C.c_int]
     L.coral_set_scan_variant.restype = C.c_int
+    L.coral_time_stream_read.argtypes = [P, C.c_longlong, P, C.c_int, C.POINTER(C.c_float), P]
+    L.coral_time_stream_read.restype = C.c_int
+    L.coral_first_seen_rows.argtypes = [C.c_int64, C.c_int32, P, P]
+    L.coral_first_seen_rows.restype = C.c_int
     L.coral_cluster_first_fit.argtypes = [C.c_int64, P, P, C.c_int64, P, C.POINTER(C.c_int32)]
     L.coral_cluster_first_fit.restype = C.c_int
     L.coral_bam_decode_open.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]

@@ -113,9 +113,12 @@ def build_chimeric_table(dr) -> ChimericTable:
     row_name = nid[all_rec_of_row[row_idx]]
     fields = np.column_stack([row_name, dr.h_sa[row_idx].astype(np.int64), dr.h_sa_nm[row_idx].astype(np.int64)])
     # first-seen de-duplication by string equality == equality of all tokens (ibg:146-151)
-    _, first = np.unique(fields, axis=0, return_index=True)
-    first.sort()
-    fields = fields[first]
+    from . import _lib
+    fields = np.ascontiguousarray(fields)
+    is_first = np.empty(len(fields), dtype=np.uint8)
+    _lib.check(_lib.lib().coral_first_seen_rows(len(fields), fields.shape[1], fields.ctypes.data, is_first.ctypes.data),
+               "coral_first_seen_rows")
+    fields = fields[is_first.astype(bool)]
     row_name = fields[:, 0]
     # dict insertion order: first SA-bearing record of each name
     u, f = np.unique(row_name, return_index=True)

@@ -75,3 +75,44 @@ extern "C" int coral_cluster_first_fit(int64_t n, const int64_t *p1, const int64
     *n_clusters = (int32_t)cl.size();
     return CORAL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// coral_first_seen_rows — mark the first occurrence of every distinct row of an int64 matrix (row-major),
+// in input order.  Exact: rows are compared column by column on every hash hit (open addressing, linear probing).
+// Restates the per-read "if sa not in list: append" de-duplication of
+// /root/reference/src/infer_breakpoint_graph.py:146-151 for all reads at once (the read name id is column 0).
+// ---------------------------------------------------------------------------------------------
+extern "C" int coral_first_seen_rows(int64_t n, int32_t ncols, const int64_t *rows, uint8_t *is_first) {
+    if (n < 0 || ncols <= 0 || (n > 0 && (!rows || !is_first))) return CORAL_ERR_ARG;
+    size_t cap = 16;
+    while (cap < (size_t)n * 2) cap <<= 1;
+    std::vector<int64_t> table(cap, -1);
+    const size_t mask = cap - 1;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t *r = rows + (size_t)i * (size_t)ncols;
+        uint64_t h = 0x9E3779B97F4A7C15ull;
+        for (int c = 0; c < ncols; ++c) {
+            h ^= (uint64_t)r[c] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+            h *= 0xBF58476D1CE4E5B9ull;
+        }
+        size_t slot = (size_t)(h ^ (h >> 31)) & mask;
+        bool first = true;
+        for (;;) {
+            const int64_t j = table[slot];
+            if (j < 0) {
+                table[slot] = i;
+                break;
+            }
+            const int64_t *q = rows + (size_t)j * (size_t)ncols;
+            bool same = true;
+            for (int c = 0; c < ncols && same; ++c) same = q[c] == r[c];
+            if (same) {
+                first = false;
+                break;
+            }
+            slot = (slot + 1) & mask;
+        }
+        is_first[i] = first ? 1 : 0;
+    }
+    return CORAL_OK;
+}

@@ -161,6 +161,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan(
     }
 }
 
+__device__ __forceinline__ cquad_t pad_or(const cquad_t *__restrict__ q, long long i, long long n) {
+    cquad_t v = {0u, 0u, 0u, 0u};
+    if (i < n) v = q[i];
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1 (variant 2)  same contract as k_cigar_scan, restructured for the memory system:
 //   * the (record, chunk) sequence of a wave is flattened and the loads run TWO chunks (2 KiB per wave)
@@ -189,8 +195,8 @@ __device__ __forceinline__ int wave_sum_dpp(int x) {
     return __builtin_amdgcn_readlane(wave_incl_scan_add_dpp(x), 63);
 }
 
-#define BATCH 4   // chunks (KiB) a wave loads back to back: 4 KiB per wave in flight while the previous 4 KiB are processed
-
+// BATCH = chunks (KiB) a wave loads back to back: BATCH KiB per wave in flight while the previous batch is processed
+template <int BATCH>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
     long long n_rec, const int32_t *__restrict__ pos, const int32_t *__restrict__ flagmq,
     const int32_t *__restrict__ n_cigar, const int64_t *__restrict__ cigar_off,
@@ -269,7 +275,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
     while (pr < n_rec) {
         // Touch the current batch: the compiler places its wait for these registers HERE, i.e. before the next
         // batch is issued, so the next 4 KiB stay in flight for the whole of this batch's arithmetic.
-        asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) asm volatile("" : "+v"(cur[j]));
         f_fetch(nxt);
         f_step();
 
@@ -371,9 +378,41 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
     }
 }
 
+// Streaming-read probe: what a plain grid-stride 16-byte-per-lane read of the same CIGAR bytes achieves
+// (upper bound for any kernel that must touch every op once).
+__global__ __launch_bounds__(256) void k_stream_probe(const cquad_t *__restrict__ q, long long n_quads, uint32_t *__restrict__ out) {
+    const long long stride = (long long)gridDim.x * 256 * 4;
+    uint32_t acc = 0;
+    for (long long i = (long long)blockIdx.x * 256 * 4 + threadIdx.x; i < n_quads; i += stride) {
+        cquad_t a = q[i], b = pad_or(q, i + 256, n_quads), c = pad_or(q, i + 512, n_quads), d = pad_or(q, i + 768, n_quads);
+        acc += a[0] ^ a[1] ^ a[2] ^ a[3] ^ b[0] ^ b[1] ^ b[2] ^ b[3] ^ c[0] ^ c[1] ^ c[2] ^ c[3] ^ d[0] ^ d[1] ^ d[2] ^ d[3];
+    }
+    if (acc == 0x9e3779b9u) out[0] = acc;      // never true in practice; keeps the loads alive
+}
+
+extern "C" int coral_time_stream_read(const uint32_t *cigar, long long n_words, uint32_t *scratch, int iters, float *ms, void *stream) {
+    if (!cigar || !scratch || !ms || iters < 1) return set_err(CORAL_ERR_ARG, "time_stream_read: bad arguments");
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipEventRecord(a, s);
+    for (int i = 0; i < iters; ++i)
+        hipLaunchKernelGGL(k_stream_probe, dim3(2048), dim3(256), 0, s, reinterpret_cast<const cquad_t *>(cigar), n_words / 4, scratch);
+    (void)hipEventRecord(b, s);
+    hipError_t e = hipEventSynchronize(b);
+    float t = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, a, b);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    if (e != hipSuccess) return hip_err(e, "time_stream_read");
+    *ms = t / (float)iters;
+    return CORAL_OK;
+}
+
 static int g_scan_variant = 2;
 extern "C" int coral_set_scan_variant(int v) {
-    if (v != 1 && v != 2) return CORAL_ERR_ARG;
+    if (v < 1 || v > 4) return CORAL_ERR_ARG;
     g_scan_variant = v;
     return CORAL_OK;
 }
@@ -408,10 +447,16 @@ extern "C" int coral_cigar_scan(const coral_records_t *rec, int32_t min_gap, int
         hipLaunchKernelGGL(k_cigar_scan, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
                            (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
                            (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
+#define LAUNCH_V2(B)                                                                                                  \
+    hipLaunchKernelGGL(k_cigar_scan_v2<B>, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,     \
+                       (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,        \
+                       (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap)
+    else if (g_scan_variant == 3)
+        LAUNCH_V2(8);
+    else if (g_scan_variant == 4)
+        LAUNCH_V2(2);
     else
-        hipLaunchKernelGGL(k_cigar_scan_v2, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
-                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
-                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
+        LAUNCH_V2(4);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_err(e, "cigar_scan launch");
     return CORAL_OK;
@@ -620,21 +665,40 @@ __global__ __launch_bounds__(COV_BLOCK) void k_point_cover(
     const int32_t *__restrict__ end, int n_pts, const int32_t *__restrict__ pt_tid,
     const int32_t *__restrict__ pt_pos, unsigned long long *__restrict__ pairs,
     uint32_t *__restrict__ pair_count, uint32_t pair_cap) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const long long stride = (long long)gridDim.x * COV_BLOCK;
-    for (long long r = (long long)blockIdx.x * COV_BLOCK + threadIdx.x; r < n_rec; r += stride) {
-        const int t = tid[r], p = pos[r], e = end[r];
-        if (t < 0) continue;
-        // first point with (pt_tid, pt_pos) >= (t, p)
-        int lo = 0, hi = n_pts;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            const int pt = pt_tid[mid];
-            const bool ge = (pt > t) || (pt == t && pt_pos[mid] >= p);
-            if (ge) hi = mid; else lo = mid + 1;
+    const long long n_round = (n_rec + stride - 1) / stride * stride;      // whole waves stay in the loop (ballots)
+    for (long long r = (long long)blockIdx.x * COV_BLOCK + threadIdx.x; r < n_round; r += stride) {
+        int j = n_pts, t = -1, e = 0;
+        if (r < n_rec) {
+            t = tid[r];
+            const int p = pos[r];
+            e = end[r];
+            if (t >= 0) {        // first point with (pt_tid, pt_pos) >= (t, p)
+                int lo = 0, hi = n_pts;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const int pt = pt_tid[mid];
+                    const bool ge = (pt > t) || (pt == t && pt_pos[mid] >= p);
+                    if (ge) hi = mid; else lo = mid + 1;
+                }
+                j = lo;
+            }
         }
-        for (int j = lo; j < n_pts && pt_tid[j] == t && pt_pos[j] < e; ++j) {
-            const uint32_t slot = atomicAdd(pair_count, 1u);
-            if (slot < pair_cap) pairs[slot] = ((unsigned long long)(uint32_t)j << 32) | (unsigned long long)(uint32_t)r;
+        // emit one covered point per round: ballot + popcount gives each lane its slot, one atomic per wave
+        for (;;) {
+            const bool hit = j < n_pts && pt_tid[j] == t && pt_pos[j] < e;
+            const unsigned long long m = __ballot(hit);
+            if (m == 0ull) break;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(pair_count, (uint32_t)__popcll(m));
+            base = __shfl(base, 0);
+            if (hit) {
+                const uint32_t slot = base + (uint32_t)__popcll(m & below);
+                if (slot < pair_cap) pairs[slot] = ((unsigned long long)(uint32_t)j << 32) | (unsigned long long)(uint32_t)r;
+                ++j;
+            }
         }
     }
 }

@@ -24,6 +24,7 @@ import logging
 import math
 import sys
 import time
+from operator import itemgetter
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -462,9 +463,17 @@ class bam_to_breakpoint_nanopore():
         return len(self.new_bp_list) - 1
 
     # -- candidate clusters -> breakpoints ---------------------------------------------------------
+    def _names_of(self, ids) -> list:
+        """Read-name strings of an array of name ids (C-level lookup)."""
+        ids = ids.tolist() if hasattr(ids, "tolist") else list(ids)
+        if not ids:
+            return []
+        if len(ids) == 1:
+            return [self.rec.names[ids[0]]]
+        return list(itemgetter(*ids)(self.rec.names))
+
     def _read_tuples(self, c: Candidates, idx):
-        names = self.rec.names
-        return [(names[r], int(i), int(j)) for r, i, j in zip(c.read[idx], c.i[idx], c.j[idx])]
+        return list(zip(self._names_of(c.read[idx]), c.i[idx].tolist(), c.j[idx].tolist()))
 
     def _call_breakpoints(self, c: Candidates, advance_subcluster: bool):
         """Cluster the candidates and yield (bp list, support tuples, stats) for every accepted (sub)cluster.
@@ -544,7 +553,7 @@ class bam_to_breakpoint_nanopore():
             rr = e_read[ko[s:e]]
             _, f = np.unique(rr, return_index=True)
             ordered = rr[np.sort(f)]                    # each read once, in first-visit order
-            per_key[int(ks[s])] = set([names[r] for r in ordered])
+            per_key[int(ks[s])] = set(itemgetter(*ordered.tolist())(names)) if len(ordered) > 1 else set([names[ordered[0]]])
         for t in chrom_order:
             reach[chroms[t]] = {}
         for k, st_ in per_key.items():
@@ -591,7 +600,7 @@ class bam_to_breakpoint_nanopore():
                     ns, ne = by[c][b0][1], by[c][b1][2]
                     tgt = [c, ns, ne]
                     here = self.amplicon_intervals[cur]
-                    reads = np.array([self._chim_index[rn] for rn in grp_names], dtype=np.int64)   # set order (Q21)
+                    reads = np.fromiter(map(self._chim_index.__getitem__, grp_names), dtype=np.int64, count=len(grp_names))   # set order (Q21)
                     cands = candidates_between(T, reads, (self._tid_of[c], ns, ne),
                                                (self._tid_of[here[0]], here[1], here[2]), self._chr_rank,
                                                self.min_bp_match_cutoff_, 20)
@@ -786,13 +795,16 @@ class bam_to_breakpoint_nanopore():
             o = np.argsort(rank[inv], kind="stable")
             grp = rank[inv][o]
             k_in = np.arange(len(o)) - np.searchsorted(grp, grp, side="left")
-            names = dr.names
             chroms = dr.header_chroms
             lia = self.large_indel_alignments
-            for q, kk in zip(o, k_in):
-                r = rec[q]
-                lia.setdefault(names[nid[q]], []).append([chroms[dr.h_tid[r]], int(nxt[q]), int(prv[q]), int(b0[q]),
-                                                         int(b1[q]), int(dr.h_mapq[r])])
+            ro = rec[o]
+            rows = list(map(list, zip(itemgetter(*dr.h_tid[ro].tolist())(chroms) if len(o) > 1 else [chroms[dr.h_tid[ro[0]]]],
+                                      nxt[o].tolist(), prv[o].tolist(), b0[o].tolist(), b1[o].tolist(),
+                                      dr.h_mapq[ro].tolist())))
+            starts = np.nonzero(k_in == 0)[0].tolist() + [len(o)]
+            gnames = self._names_of(nid[o][starts[:-1]])
+            for gi, nm in enumerate(gnames):                       # names are distinct per group (grouped above)
+                lia[nm] = rows[starts[gi]:starts[gi + 1]]
             a = nxt[o]
             b = np.minimum(prv[o], a)                                            # aliasing swap (Q7)
             tid = dr.h_tid[rec[o]].astype(np.int64)
@@ -906,8 +918,8 @@ class bam_to_breakpoint_nanopore():
                         rbps.add(t[0])
             both = np.intersect1d(np.intersect1d(rls, rrs, assume_unique=True),
                                   np.intersect1d(rls1, rrs1, assume_unique=True), assume_unique=True)
-            e[9] = set([names[i] for i in np.union1d(rls, rrs)])
-            e[8] = sum(1 for i in both if names[i] not in rbps) if rbps else int(len(both))
+            e[9] = set(self._names_of(np.union1d(rls, rrs)))
+            e[8] = sum(1 for nm in self._names_of(both) if nm not in rbps) if rbps else int(len(both))
 
     def compute_path_constraints(self):
         raise NotImplementedError("path constraints belong to the cycle-decomposition step (SURVEY.md §8(f) item 2)")

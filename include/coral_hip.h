@@ -119,8 +119,12 @@ int coral_time_cigar_scan(const coral_records_t *rec, int32_t min_gap, int32_t m
                           int32_t *gaps, uint32_t *gap_count, uint32_t gap_cap, int32_t iters,
                           float *ms_per_launch, void *stream);
 
-/* Tuning hook for A/B measurements: 1 = first cigar_scan kernel, 2 = prefetching DPP variant (default). */
+/* Tuning hooks for A/B measurements: variant 1 = first cigar_scan kernel, 2 = batched prefetching DPP kernel with
+ * 4 KiB per wave in flight (default), 3 = the same with 8 KiB, 4 = with 2 KiB.  coral_time_stream_read times a plain
+ * grid-stride 16-byte-per-lane read of n_words uint32 (the ceiling for a kernel that touches every op once). */
 int coral_set_scan_variant(int variant);
+int coral_time_stream_read(const uint32_t *cigar, long long n_words, uint32_t *scratch, int iters, float *ms,
+                           void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * coral_cluster_first_fit — HOST function (no device work).
@@ -132,6 +136,14 @@ int coral_set_scan_variant(int variant);
  * ------------------------------------------------------------------------------------------------ */
 int coral_cluster_first_fit(int64_t n, const int64_t *p1, const int64_t *p2, int64_t cutoff,
                             int32_t *cluster_of, int32_t *n_clusters);
+
+/* ------------------------------------------------------------------------------------------------
+ * coral_first_seen_rows — HOST function.  is_first[i] = 1 iff row i of the row-major int64 matrix rows[n][ncols]
+ * differs from every earlier row.  With the read-name id in column 0 and the tokenised SA entry in the others this
+ * is the "if sa not in chimeric_alignments[rn]: append" de-duplication of
+ * /root/reference/src/infer_breakpoint_graph.py:146-151, for all reads at once, exact (no hash-only equality).
+ * ------------------------------------------------------------------------------------------------ */
+int coral_first_seen_rows(int64_t n, int32_t ncols, const int64_t *rows, uint8_t *is_first);
 
 /* ------------------------------------------------------------------------------------------------
  * coral_bam_decode_* — HOST functions: BAM/BGZF file -> structure-of-arrays records, decoded ONCE.

@@ -25,8 +25,13 @@ rs = dr.c_struct()
 mb = torch.empty(dr.n, dtype=torch.int32, device="cuda"); qi = torch.empty_like(mb); b0 = torch.empty_like(mb); b1 = torch.empty_like(mb)
 gaps = torch.empty((1 << 20, 4), dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
 ms = C.c_float(0)
-for it in range(6):
-    L.coral_set_scan_variant(1 + it % 2)
+for it in range(12):
+    L.coral_set_scan_variant(1 + it % 4)
     _lib.check(L.coral_time_cigar_scan(C.byref(rs), 600, 20, mb.data_ptr(), qi.data_ptr(), b0.data_ptr(), b1.data_ptr(), gaps.data_ptr(), cnt.data_ptr(), 1 << 20, 10, C.byref(ms), dr.stream()), "time")
     B = dr.algorithmic_bytes()
-    print("variant %d" % (1 + it % 2), "scan %.3f ms/launch  alg bytes %.3f GB  -> %.1f GB/s (%.1f%% of 8 TB/s)" % (ms.value, B / 1e9, B / ms.value / 1e6, B / ms.value / 1e6 / 80), flush=True)
+    print("variant %d" % (1 + it % 4), "scan %.3f ms/launch  alg bytes %.3f GB  -> %.1f GB/s (%.1f%% of 8 TB/s)" % (ms.value, B / 1e9, B / ms.value / 1e6, B / ms.value / 1e6 / 80), flush=True)
+
+scr = torch.zeros(4, dtype=torch.int32, device="cuda")
+for it in range(3):
+    _lib.check(L.coral_time_stream_read(dr.cigar.data_ptr(), dr.cigar.numel(), scr.data_ptr(), 10, C.byref(ms), dr.stream()), "stream")
+    print("plain streaming read %.3f ms  -> %.1f GB/s" % (ms.value, dr.cigar.numel() * 4 / ms.value / 1e6), flush=True)
