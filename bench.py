@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--reads", type=int, default=0, help="override the read count of the config (0 = as configured)")
     ap.add_argument("--cpu-sample", type=int, default=50000, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of N > 1)")
+    ap.add_argument("--shared-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     a = ap.parse_args()
 
     import torch
@@ -36,11 +38,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    if a.shared_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(a.backend)
 
     from coral_amd import synth, kernels
     from coral_amd import infer_breakpoint_graph as ibg
@@ -85,7 +92,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     scan_ms = [e0.elapsed_time(e1) for e0, e1 in kernels.PROFILE["scan_ms"]]
@@ -104,8 +111,8 @@ def main():
                        "records": int(dr.n_total), "cigar_ops": int(dr.total_ops_all), "amplicons": len(b.lr_graph),
                        "discordant_edges": sum(len(g.discordant_edges) for g in b.lr_graph),
                        "generate_s": round(gen_s, 2), "parallelism": "records sharded over %d GPU(s)" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_cigar_scan", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None, "launch_ms": scan_ms_avg,
+            "roofline": {"bound": "hbm", "kernel": "k_cigar_scan_v2<4>", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": pmc_traffic(cfg, world), "launch_ms": scan_ms_avg,
                          "algorithmic_bytes_per_launch": int(alg_bytes_local)},
         }
         if a.cpu_sample and world == 1:
@@ -115,6 +122,19 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     shutil.rmtree(work, ignore_errors=True)
+
+
+def pmc_traffic(cfg, world):
+    """HBM bytes per scan launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json) when they
+    were taken on exactly this workload on one GPU; counters cannot be collected from inside this process -> else None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fp:
+            p = json.load(fp)
+        if world == 1 and p["workload"] == cfg.name and p["n_reads"] == cfg.n_reads:
+            return p["kernels"][p["scan_kernel"]]["hbm_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def cpu_baseline(config, n_sample, work):

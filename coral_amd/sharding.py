@@ -27,8 +27,15 @@ def command(dr, cmd):
     dist.broadcast_object_list([cmd], src=0, group=dr.group)
 
 
+def _via_host(dr, t: torch.Tensor) -> bool:
+    """gloo cannot all-gather device tensors: stage through host memory (CPU tests / single-GPU rehearsal only)."""
+    return t.is_cuda and dist.get_backend(dr.group) == "gloo"
+
+
 def allgather_rows(dr, rows: torch.Tensor) -> torch.Tensor:
     """All-gather-v of an int64 [k, c] row tensor (k differs per rank), concatenated in rank order."""
+    if _via_host(dr, rows):
+        return allgather_rows(dr, rows.cpu()).to(rows.device)
     dev = rows.device
     k = torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev)
     ks = [torch.zeros_like(k) for _ in range(dr.world)]
@@ -46,6 +53,10 @@ def allgather_rows(dr, rows: torch.Tensor) -> torch.Tensor:
 
 
 def allreduce_sum(dr, t: torch.Tensor) -> torch.Tensor:
+    if _via_host(dr, t):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=dr.group)
+        return h.to(t.device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=dr.group)
     return t
 
