@@ -763,3 +763,94 @@ def records_from_alignments(alns: Sequence[dict], device="cpu") -> Records:
                    nonacgt_rec=t64(na_rec), nonacgt_pos=t32(na_pos), n_names=len(names),
                    name_gid=torch.arange(len(names), dtype=torch.int64, device=dev),
                    names=[k for k, _ in sorted(names.items(), key=lambda kv: kv[1])])
+
+
+def merge_sorted(a: Records, b: Records) -> Records:
+    """Concatenate two record stores (same header) and restore (tid, pos) order (stable: ``a`` before ``b``)."""
+    assert a.header_chroms == b.header_chroms
+    na = a.materialise_names()
+    nb = b.materialise_names()
+    n = a.n + b.n
+    cat = lambda k: torch.cat([getattr(a, k).cpu(), getattr(b, k).cpu()])
+    tid, pos = cat("tid").to(torch.int64), cat("pos").to(torch.int64)
+    perm = torch.argsort(tid * (1 << 32) + pos, stable=True)
+    # names: first-appearance order over the merged, sorted records
+    all_names = [na[i] for i in a.name_id.tolist()] + [nb[i] for i in b.name_id.tolist()]
+    ids: Dict[str, int] = {}
+    name_id = []
+    for i in perm.tolist():
+        name_id.append(ids.setdefault(all_names[i], len(ids)))
+    # ragged pieces
+    def ragged(off_a, off_b, data_a, data_b):
+        cnt = torch.cat([off_a[1:] - off_a[:-1], off_b[1:] - off_b[:-1]]).cpu()
+        start = torch.cat([off_a[:-1].cpu(), off_b[:-1].cpu() + data_a.shape[0]])
+        data = torch.cat([data_a.cpu(), data_b.cpu()])
+        cp, sp = cnt[perm], start[perm]
+        owner, within = _ragged_arange(cp)
+        new_off = torch.zeros(n + 1, dtype=torch.int64)
+        new_off[1:] = torch.cumsum(cp, 0)
+        return new_off, data[sp[owner] + within]
+    cig_off, cig = ragged(a.cigar_off, b.cigar_off, a.cigar, b.cigar)
+    sa_off, sa = ragged(a.sa_off, b.sa_off, a.sa, b.sa)
+    _, sa_nm = ragged(a.sa_off, b.sa_off, a.sa_nm, b.sa_nm)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(n)
+    na_rec = inv[torch.cat([a.nonacgt_rec.cpu(), b.nonacgt_rec.cpu() + a.n])]
+    na_pos = cat("nonacgt_pos")
+    o = torch.argsort(na_rec, stable=True)
+    g = lambda k: cat(k)[perm]
+    return Records(n=n, tid=g("tid"), pos=g("pos"), end=g("end"), flag=g("flag"), mapq=g("mapq"), qlen=g("qlen"),
+                   has_seq=g("has_seq"), nm=g("nm"), name_id=torch.tensor(name_id, dtype=torch.int32), n_cigar=g("n_cigar"),
+                   cigar_off=cig_off, cigar=cig, sa_off=sa_off, sa=sa, sa_nm=sa_nm, nonacgt_rec=na_rec[o], nonacgt_pos=na_pos[o],
+                   n_names=len(ids), name_gid=torch.arange(len(ids), dtype=torch.int64),
+                   names=[k for k, _ in sorted(ids.items(), key=lambda kv: kv[1])],
+                   header_chroms=list(a.header_chroms), header_lens=list(a.header_lens))
+
+
+def _edge_alignments(cfg: SynthConfig) -> List[dict]:
+    """Hand-written records injected into the 'tiny' data set: the corner cases of the reference's loops."""
+    M, I, D, N, S, H, P, EQ, X = range(9)
+    seg = cfg.circles[0]
+    a, b = seg[0], seg[1]                     # two amplicon segments on chr8
+    t = a.tid
+    base = a.start + 60_000
+    out = []
+    # (1) chimeric read WITHOUT a primary record: two supplementary records pointing at each other -> dropped (ibg:163-173)
+    out += [dict(tid=t, pos=base, flag=2048, name="edge_noprimary", cigar=[(M, 3000), (H, 2000)],
+                 sa=[(t, b.start + 501, 0, 3000, 2000, 0, 0, 60, 3)]),
+            dict(tid=t, pos=b.start + 500, flag=2048, name="edge_noprimary", cigar=[(H, 3000), (M, 2000)],
+                 sa=[(t, base + 1, 0, 0, 3000, 0, 2000, 60, 2)])]
+    # (2) SA entry without soft clip ("2000M"): the read's value becomes ([], [], []) (cp:248-253)
+    out += [dict(tid=t, pos=base + 100, flag=0, name="edge_noS", cigar=[(M, 3000), (S, 2000)], nm=5,
+                 sa=[(t, b.start + 801, 0, 0, 0, 0, 0, 60, 1)])]
+    # (3) placed unmapped read without CIGAR inside the amplicon, and an unplaced one (tid -1 is not emitted: whole-file
+    #     fetch skips it) -> name sets of point fetches include the placed one, read counts do not
+    out += [dict(tid=t, pos=base + 200, flag=4, name="edge_unmapped", cigar=[], qlen=500, mapq=0)]
+    # (4) N (reference skip) and =/X ops; a 700-bp N gap counts as a large gap (get_blocks advances over N)
+    out += [dict(tid=t, pos=base + 300, name="edge_N_%d" % k, nm=9 + k,
+                 cigar=[(S, 10), (EQ, 800), (X, 3), (EQ, 400), (N, 700 + k), (M, 900), (I, 2), (M, 600)]) for k in range(4)]
+    # (5) two large deletions in ONE record (indices 0 and 1 of its list), shared by four reads
+    out += [dict(tid=t, pos=base + 5000 + k, name="edge_2del_%d" % k, nm=20,
+                 cigar=[(M, 1500 - k), (D, 900), (M, 2000), (D, 1200), (M, 1500)]) for k in range(4)]
+    # (6) the same big deletion in a MAPQ-19 record: ignored (ibg:754)
+    out += [dict(tid=t, pos=base + 5000, name="edge_lowmapq", mapq=19, cigar=[(M, 1500), (D, 900), (M, 2000)])]
+    # (7) chimeric read with one piece on a chromosome that has no CN segments (chr1): cniset {-1} (ibg:209-210)
+    out += [dict(tid=t, pos=base + 9000, flag=0, name="edge_chr1", cigar=[(M, 4000), (S, 3000)], nm=4,
+                 sa=[(0, 1_000_001, 1, 0, 3000, 0, 4000, 60, 2)]),
+            dict(tid=0, pos=1_000_000, flag=2064, name="edge_chr1", cigar=[(M, 3000), (H, 4000)], nm=2,
+                 sa=[(t, base + 9001, 0, 0, 4000, 0, 3000, 60, 4)])]
+    # (8) adjacent D ops that only TOGETHER exceed 600 bp, and a 600-bp gap that must not count
+    out += [dict(tid=t, pos=base + 12000, name="edge_adjD", cigar=[(M, 700), (D, 300), (D, 301), (M, 700)]),
+            dict(tid=t, pos=base + 12010, name="edge_600", cigar=[(M, 700), (D, 600), (M, 700)])]
+    return sorted(out, key=lambda r: (r["tid"], r["pos"]))
+
+
+def dataset(name: str, device="cpu") -> Tuple[SynthConfig, Records]:
+    """Named data set = configuration + records ('tiny_edge' = 'tiny' plus hand-written corner-case records)."""
+    if name == "tiny_edge":
+        cfg = named_config("tiny")
+        cfg.name = "tiny_edge"
+        rec = merge_sorted(generate(cfg, "cpu"), records_from_alignments(_edge_alignments(cfg)))
+        return cfg, (rec if str(device) == "cpu" else rec.to(device))
+    cfg = named_config(name)
+    return cfg, generate(cfg, device)

@@ -84,8 +84,7 @@ def main():
 
     from coral_amd import synth
     from oracle.refharness import fake_pysam
-    cfg = synth.named_config(a.config)
-    rec = synth.generate(cfg, "cpu")
+    cfg, rec = synth.dataset(a.config, "cpu")
     _install_stubs()
     tmp = tempfile.mkdtemp(prefix="coral_ref_")
     bam = os.path.join(tmp, "synthetic.bam")

@@ -22,8 +22,7 @@ def main():
     from coral_amd.breakpoint_graph import graph_text
     from tests.product_check import install_cpu_kernel_fakes
     install_cpu_kernel_fakes(_Patch())
-    cfg = synth.named_config(case)
-    rec = synth.generate(cfg, "cpu")
+    cfg, rec = synth.dataset(case, "cpu")
     cn, seeds = os.path.join(outdir, "cn%d.bed" % rank), os.path.join(outdir, "seeds%d.bed" % rank)
     synth.write_cn_bed(cfg, cn)
     synth.write_seed_bed(cfg, seeds)

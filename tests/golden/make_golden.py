@@ -28,6 +28,7 @@ E2E_CASES = [
     ("tiny", []),
     ("tiny", ["--output_bp"]),
     ("tiny", ["--min_bp_support", "30.0"]),
+    ("tiny_edge", []),
     ("small", []),
     ("ultra", []),
 ]

@@ -17,9 +17,7 @@ def load_case(golden_dir, case):
         gold = json.load(fp)
     name = gold["config"]
     if name not in _cache:
-        cfg = synth.named_config(name)
-        rec = synth.generate(cfg, "cpu")
-        _cache[name] = (cfg, rec)
+        _cache[name] = synth.dataset(name, "cpu")
     cfg, rec = _cache[name]
     assert records_digest(rec) == gold["records_sha256"], "synthetic inputs changed: regenerate the goldens"
     return gold, cfg, rec

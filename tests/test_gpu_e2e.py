@@ -11,7 +11,7 @@ from coral_amd import synth
 from tests.product_check import HASHSEED0, check_product_against_golden
 
 pytestmark = pytest.mark.gpu
-CASES = ["tiny", "tiny_output_bp", "tiny_min_bp_support_30p0", "small", "ultra"]
+CASES = ["tiny", "tiny_output_bp", "tiny_min_bp_support_30p0", "tiny_edge", "small", "ultra"]
 
 
 @pytest.mark.parametrize("case", CASES)

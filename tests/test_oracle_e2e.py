@@ -14,7 +14,7 @@ from oracle import coral_oracle as O
 from oracle.hostrecords import HostRecords
 from tests.canon import canon, graph_snapshot, records_digest, strip_cn
 
-CASES = ["tiny", "tiny_output_bp", "tiny_min_bp_support_30p0", "small", "ultra"]
+CASES = ["tiny", "tiny_output_bp", "tiny_min_bp_support_30p0", "tiny_edge", "small", "ultra"]
 HASHSEED0 = os.environ.get("PYTHONHASHSEED") == "0"
 _cache = {}
 
@@ -24,8 +24,7 @@ def load_case(golden_dir, case):
         gold = json.load(fp)
     cfg_name = gold["config"]
     if cfg_name not in _cache:
-        cfg = synth.named_config(cfg_name)
-        rec = synth.generate(cfg, "cpu")
+        cfg, rec = synth.dataset(cfg_name, "cpu")
         _cache[cfg_name] = (cfg, rec, HostRecords(rec))
     cfg, rec, host = _cache[cfg_name]
     assert records_digest(rec) == gold["records_sha256"], "synthetic inputs changed: regenerate the goldens"

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("case", ["tiny", "small"])
+@pytest.mark.parametrize("case", ["tiny_edge", "small"])
 def test_two_rank_shard_merge_equals_reference(case, golden_dir, tmp_path):
     port = _free_port()
     procs = []
