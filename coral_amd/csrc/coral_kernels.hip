@@ -196,7 +196,7 @@ __device__ __forceinline__ int wave_sum_dpp(int x) {
 }
 
 // BATCH = chunks (KiB) a wave loads back to back: BATCH KiB per wave in flight while the previous batch is processed
-template <int BATCH>
+template <int BATCH, bool LIGHT = false>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
     long long n_rec, const int32_t *__restrict__ pos, const int32_t *__restrict__ flagmq,
     const int32_t *__restrict__ n_cigar, const int64_t *__restrict__ cigar_off,
@@ -280,6 +280,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
         f_fetch(nxt);
         f_step();
 
+        if (LIGHT) {      // diagnostic build: same cursors and loads, no arithmetic (isolates the access pattern)
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) msum += (int)(cur[j][0] ^ cur[j][1] ^ cur[j][2] ^ cur[j][3]);
+        } else
 #pragma unroll
         for (int j = 0; j < BATCH; ++j) {
             if (j > 0 && pc + j * WAVE >= pnq) break;        // wave-uniform
@@ -378,6 +382,195 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K1 (variant 6, "flat")  every wave owns a CONTIGUOUS RANGE OF WHOLE RECORDS holding ~1/n_waves of all ops and
+// streams that range as one flat run of 16-byte quads (the access pattern that reaches the plain-read rate), BATCH
+// KiB in flight ahead of the arithmetic.  Record boundaries are quad-aligned (the layout pads every record), so a
+// chunk that contains a boundary is simply processed once per record with the other record's lanes masked to
+// padding.  Same outputs as the other variants.
+// ---------------------------------------------------------------------------------------------
+struct RecState {
+    int carry_ref, carry_end, msum, qsum, first;
+};
+
+__device__ __forceinline__ void scan_chunk(const cquad_t b0, const int lane, RecState &st, const bool gaps_on, const int min_gap,
+                                           const int rec, const int quad_in_rec, const int p0, int32_t *__restrict__ gaps,
+                                           uint32_t *__restrict__ gap_count, const uint32_t gap_cap) {
+    const unsigned long long OPCLASS = 0x0000000770441147ull;
+    int len[4], adv[4], aend[4], ref[4];
+    bool aln[4];
+    int tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t w = b0[k];
+        const uint32_t f = (uint32_t)(OPCLASS >> ((w << 2) & 60u));
+        len[k] = (int)(w >> 4);
+        adv[k] = len[k] & -(int)(f & 1u);
+        const int alen = len[k] & -(int)((f >> 1) & 1u);
+        aln[k] = (f >> 1) & 1u;
+        aend[k] = alen;
+        st.msum += alen;
+        st.qsum += len[k] & -(int)((f >> 2) & 1u);
+        tot += adv[k];
+    }
+    const int incl = wave_incl_scan_add_dpp(tot);
+    ref[0] = st.carry_ref + incl - tot;
+    ref[1] = ref[0] + adv[0];
+    ref[2] = ref[1] + adv[1];
+    ref[3] = ref[2] + adv[2];
+    int run[4];
+    run[0] = aln[0] ? ref[0] + aend[0] : 0;
+    run[1] = aln[1] ? ref[1] + aend[1] : run[0];
+    run[2] = aln[2] ? ref[2] + aend[2] : run[1];
+    run[3] = aln[3] ? ref[3] + aend[3] : run[2];
+    int mx = run[3];
+    mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x111, 0xf, 0xf, true));
+    mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x112, 0xf, 0xf, true));
+    mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x114, 0xf, 0xf, true));
+    mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x118, 0xf, 0xf, true));
+    mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x142, 0xa, 0xf, true));
+    mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x143, 0xc, 0xf, true));
+    const int shifted = __builtin_amdgcn_update_dpp(st.carry_end, mx, 0x138, 0xf, 0xf, false);   // wave_shr:1
+    const int prev_in = max(shifted, st.carry_end);
+    if (st.carry_end == 0) {
+        const unsigned long long has = __ballot(run[3] != 0);
+        if (has != 0ull) {
+            int lf = ref[3];
+            lf = aln[2] ? ref[2] : lf;
+            lf = aln[1] ? ref[1] : lf;
+            lf = aln[0] ? ref[0] : lf;
+            st.first = __builtin_amdgcn_readlane(lf, (int)__builtin_ctzll(has));
+        }
+    }
+    const int none = 0x3fffffff;
+    const int pin = prev_in == 0 ? none : prev_in;
+    const int pv1 = run[0] ? run[0] : pin, pv2 = run[1] ? run[1] : pin, pv3 = run[2] ? run[2] : pin;
+    const bool h0 = aln[0] && (ref[0] - pin > min_gap);
+    const bool h1 = aln[1] && (ref[1] - pv1 > min_gap);
+    const bool h2 = aln[2] && (ref[2] - pv2 > min_gap);
+    const bool h3 = aln[3] && (ref[3] - pv3 > min_gap);
+    if (gaps_on && __ballot(h0 | h1 | h2 | h3) != 0ull) {
+        const int pv[4] = {pin, pv1, pv2, pv3};
+        const bool hit[4] = {h0, h1, h2, h3};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (hit[k]) {
+                const uint32_t slot = atomicAdd(gap_count, 1u);
+                if (slot < gap_cap) {
+                    int4 row = make_int4(rec, (quad_in_rec + lane) * 4 + k, p0 + pv[k], p0 + ref[k]);
+                    reinterpret_cast<int4 *>(gaps)[slot] = row;
+                }
+            }
+        }
+    }
+    st.carry_ref += __builtin_amdgcn_readlane(incl, 63);
+    st.carry_end = max(st.carry_end, __builtin_amdgcn_readlane(mx, 63));
+}
+
+template <int BATCH>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_flat(
+    long long n_rec, const int32_t *__restrict__ pos, const int32_t *__restrict__ flagmq,
+    const int32_t *__restrict__ n_cigar, const int64_t *__restrict__ cigar_off,
+    const uint32_t *__restrict__ cigar, int min_gap, int min_mapq, int32_t *__restrict__ mbases,
+    int32_t *__restrict__ qinfer, int32_t *__restrict__ blk_first, int32_t *__restrict__ blk_last,
+    int32_t *__restrict__ gaps, uint32_t *__restrict__ gap_count, uint32_t gap_cap) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (SCAN_BLOCK / WAVE) + (threadIdx.x >> 6)));
+    const long long nwaves = (long long)gridDim.x * (SCAN_BLOCK / WAVE);
+    const cquad_t pad = {OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD};
+    const cquad_t *__restrict__ qbase = reinterpret_cast<const cquad_t *>(cigar);
+
+    // ---- this wave's record range [ra, rb): first record starting at or after its share of the op stream
+    const long long total = cigar_off[n_rec];
+    auto first_record_at = [&](long long target) -> long long {     // lower_bound over cigar_off[0..n_rec]
+        long long lo = 0, hi = n_rec;
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            if (cigar_off[mid] >= target) hi = mid; else lo = mid + 1;
+        }
+        return lo;
+    };
+    const long long ra = wave == 0 ? 0 : first_record_at((total / nwaves) * wave);
+    const long long rb = wave == nwaves - 1 ? n_rec : first_record_at((total / nwaves) * (wave + 1));
+    if (ra >= rb) return;            // (wave-uniform)
+    const long long s0 = cigar_off[ra] >> 2, s1 = cigar_off[rb] >> 2;      // quad range of the wave
+
+    // ---- record cursor; the next record's metadata is requested one record ahead (scalar loads)
+    long long r = ra;
+    long long rstart = s0, rend = cigar_off[ra + 1] >> 2;
+    int p0 = pos[ra];
+    bool gaps_on = ((flagmq[ra] >> 16) & 0xff) >= min_mapq;
+    long long n_off = 0;
+    int n_pos = 0, n_fm = 0;
+    const long long last_rec = n_rec - 1;
+    auto request = [&](long long rr) {
+        const long long c = rr < n_rec ? rr : last_rec;
+        n_off = cigar_off[c + 1];
+        n_pos = pos[c];
+        n_fm = flagmq[c];
+    };
+    request(ra + 1);
+    RecState st = {0, 0, 0, 0, 0};
+    auto finish_record = [&]() {
+        const int ms = wave_sum_dpp(st.msum);
+        const int qs = wave_sum_dpp(st.qsum);
+        if (lane == 0) {
+            mbases[r] = ms;
+            qinfer[r] = qs;
+            blk_first[r] = (st.carry_end > 0) ? p0 + st.first : -1;
+            blk_last[r] = (st.carry_end > 0) ? p0 + st.carry_end : -1;
+        }
+        st = {0, 0, 0, 0, 0};
+        ++r;
+        rstart = rend;
+        rend = n_off >> 2;
+        p0 = n_pos;
+        gaps_on = ((n_fm >> 16) & 0xff) >= min_mapq;
+        request(r + 1);
+    };
+
+    // ---- flat stream, BATCH KiB ahead
+    cquad_t cur[BATCH], nxt[BATCH];
+    auto fetch = [&](cquad_t (&dst)[BATCH], long long q0) {
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            dst[j] = pad;
+            const long long i = q0 + j * WAVE + lane;
+            if (i < s1) dst[j] = qbase[i];
+        }
+    };
+    fetch(cur, s0);
+    for (long long cq0 = s0; cq0 < s1; cq0 += BATCH * WAVE) {
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) asm volatile("" : "+v"(cur[j]));      // wait for this batch here, then prefetch
+        fetch(nxt, cq0 + BATCH * WAVE);
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const long long cq = cq0 + j * WAVE;
+            if (cq >= s1) break;
+            const long long cend = cq + WAVE;
+            long long seg_start = cq;
+            for (;;) {                                           // once per record present in this chunk (usually once)
+                const long long seg_end = rend < cend ? rend : cend;
+                if (seg_end > seg_start) {
+                    const long long qi = cq + lane;
+                    cquad_t b = cur[j];
+                    if (qi < seg_start || qi >= seg_end) b = pad;
+                    scan_chunk(b, lane, st, gaps_on, min_gap, (int)r, (int)(cq - rstart), p0, gaps, gap_count, gap_cap);
+                }
+                if (rend > cend) break;                          // the record continues in the next chunk
+                finish_record();
+                if (r >= rb) break;
+                seg_start = rstart;
+                if (seg_start >= cend) break;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) cur[j] = nxt[j];
+    }
+    while (r < rb) finish_record();      // records without any op at the end of the range
+}
+
 // Streaming-read probe: what a plain grid-stride 16-byte-per-lane read of the same CIGAR bytes achieves
 // (upper bound for any kernel that must touch every op once).
 __global__ __launch_bounds__(256) void k_stream_probe(const cquad_t *__restrict__ q, long long n_quads, uint32_t *__restrict__ out) {
@@ -390,6 +583,24 @@ __global__ __launch_bounds__(256) void k_stream_probe(const cquad_t *__restrict_
     if (acc == 0x9e3779b9u) out[0] = acc;      // never true in practice; keeps the loads alive
 }
 
+// Probe 2: every wave streams its own contiguous region (n_quads / n_waves quads), 4 KiB per iteration.
+__global__ __launch_bounds__(256) void k_stream_probe_regions(const cquad_t *__restrict__ q, long long n_quads, uint32_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * 4;
+    const long long per = (n_quads + nwaves - 1) / nwaves;
+    const long long a = wave * per, b = (a + per < n_quads) ? a + per : n_quads;
+    uint32_t acc = 0;
+    for (long long i = a + lane; i < b; i += 256) {
+        cquad_t x0 = q[i], x1 = pad_or(q, i + 64, b), x2 = pad_or(q, i + 128, b), x3 = pad_or(q, i + 192, b);
+        acc += x0[0] ^ x0[1] ^ x0[2] ^ x0[3] ^ x1[0] ^ x1[1] ^ x1[2] ^ x1[3] ^ x2[0] ^ x2[1] ^ x2[2] ^ x2[3] ^ x3[0] ^ x3[1] ^ x3[2] ^ x3[3];
+    }
+    if (acc == 0x9e3779b9u) out[0] = acc;
+}
+
+static int g_probe_mode = 1;
+extern "C" int coral_set_probe_mode(int m) { g_probe_mode = m; return CORAL_OK; }
+
 extern "C" int coral_time_stream_read(const uint32_t *cigar, long long n_words, uint32_t *scratch, int iters, float *ms, void *stream) {
     if (!cigar || !scratch || !ms || iters < 1) return set_err(CORAL_ERR_ARG, "time_stream_read: bad arguments");
     hipEvent_t a, b;
@@ -397,8 +608,12 @@ extern "C" int coral_time_stream_read(const uint32_t *cigar, long long n_words, 
     (void)hipEventCreate(&b);
     hipStream_t s = (hipStream_t)stream;
     (void)hipEventRecord(a, s);
-    for (int i = 0; i < iters; ++i)
-        hipLaunchKernelGGL(k_stream_probe, dim3(2048), dim3(256), 0, s, reinterpret_cast<const cquad_t *>(cigar), n_words / 4, scratch);
+    for (int i = 0; i < iters; ++i) {
+        if (g_probe_mode == 1)
+            hipLaunchKernelGGL(k_stream_probe, dim3(2048), dim3(256), 0, s, reinterpret_cast<const cquad_t *>(cigar), n_words / 4, scratch);
+        else
+            hipLaunchKernelGGL(k_stream_probe_regions, dim3(2048), dim3(256), 0, s, reinterpret_cast<const cquad_t *>(cigar), n_words / 4, scratch);
+    }
     (void)hipEventRecord(b, s);
     hipError_t e = hipEventSynchronize(b);
     float t = 0.f;
@@ -410,9 +625,9 @@ extern "C" int coral_time_stream_read(const uint32_t *cigar, long long n_words, 
     return CORAL_OK;
 }
 
-static int g_scan_variant = 2;
+static int g_scan_variant = 3;   // 8 KiB per wave in flight: best on average over the boxes measured (profiles/r01_scan_variants.md)
 extern "C" int coral_set_scan_variant(int v) {
-    if (v < 1 || v > 4) return CORAL_ERR_ARG;
+    if (v < 1 || v > 6) return CORAL_ERR_ARG;
     g_scan_variant = v;
     return CORAL_OK;
 }
@@ -451,12 +666,20 @@ extern "C" int coral_cigar_scan(const coral_records_t *rec, int32_t min_gap, int
     hipLaunchKernelGGL(k_cigar_scan_v2<B>, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,     \
                        (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,        \
                        (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap)
-    else if (g_scan_variant == 3)
-        LAUNCH_V2(8);
+    else if (g_scan_variant == 2)
+        LAUNCH_V2(4);
     else if (g_scan_variant == 4)
         LAUNCH_V2(2);
+    else if (g_scan_variant == 6)
+        hipLaunchKernelGGL(k_cigar_scan_flat<4>, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
+                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
+                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
+    else if (g_scan_variant == 5)
+        hipLaunchKernelGGL((k_cigar_scan_v2<4, true>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
+                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
+                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
     else
-        LAUNCH_V2(4);
+        LAUNCH_V2(8);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_err(e, "cigar_scan launch");
     return CORAL_OK;

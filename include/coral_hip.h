@@ -119,10 +119,12 @@ int coral_time_cigar_scan(const coral_records_t *rec, int32_t min_gap, int32_t m
                           int32_t *gaps, uint32_t *gap_count, uint32_t gap_cap, int32_t iters,
                           float *ms_per_launch, void *stream);
 
-/* Tuning hooks for A/B measurements: variant 1 = first cigar_scan kernel, 2 = batched prefetching DPP kernel with
- * 4 KiB per wave in flight (default), 3 = the same with 8 KiB, 4 = with 2 KiB.  coral_time_stream_read times a plain
+/* Tuning hooks for A/B measurements: variant 1 = first cigar_scan kernel; 2 / 3 / 4 = batched prefetching DPP kernel
+ * with 4 / 8 (default) / 2 KiB per wave in flight; 5 = diagnostic (loads only, no arithmetic, outputs invalid);
+ * 6 = "flat" kernel (each wave streams a contiguous range of whole records).  coral_time_stream_read times a plain
  * grid-stride 16-byte-per-lane read of n_words uint32 (the ceiling for a kernel that touches every op once). */
 int coral_set_scan_variant(int variant);
+int coral_set_probe_mode(int mode);   /* 1 = grid-stride probe, 2 = one contiguous region per wave */
 int coral_time_stream_read(const uint32_t *cigar, long long n_words, uint32_t *scratch, int iters, float *ms,
                            void *stream);
 

@@ -41,10 +41,16 @@ def case(request):
     return request.param, rec, HostRecords(rec), DeviceRecords(rec, "cuda:0")
 
 
-def test_cigar_scan(case):
-    from coral_amd import kernels
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6])
+def test_cigar_scan(case, variant):
+    """Every variant of the scan kernel (first version, batched per-record 2/4/8 KiB, flat contiguous ranges)."""
+    from coral_amd import kernels, _lib
     name, rec, host, dr = case
-    res = kernels.cigar_scan(dr, 600, 20, gap_cap=64)       # small cap: exercises the overflow/retry path
+    assert _lib.lib().coral_set_scan_variant(variant) == 0
+    try:
+        res = kernels.cigar_scan(dr, 600, 20, gap_cap=64)       # small cap: exercises the overflow/retry path
+    finally:
+        _lib.lib().coral_set_scan_variant(3)
     mb, qi = res.mbases.cpu().numpy(), res.qinfer.cpu().numpy()
     b0, b1 = res.blk_first.cpu().numpy(), res.blk_last.cpu().numpy()
     gaps = []

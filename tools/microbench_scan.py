@@ -19,19 +19,24 @@ L0.coral_set_scan_variant(1); r1 = kernels.cigar_scan(dr)
 L0.coral_set_scan_variant(2); res = kernels.cigar_scan(dr)
 import numpy as np
 assert torch.equal(r1.mbases, res.mbases) and torch.equal(r1.qinfer, res.qinfer) and torch.equal(r1.blk_first, res.blk_first) and torch.equal(r1.blk_last, res.blk_last) and np.array_equal(r1.gaps, res.gaps), "variants disagree"
-print("gaps", res.gaps.shape, "variants agree")
+L0.coral_set_scan_variant(6); r6 = kernels.cigar_scan(dr)
+assert torch.equal(r6.mbases, res.mbases) and torch.equal(r6.qinfer, res.qinfer) and torch.equal(r6.blk_first, res.blk_first) and torch.equal(r6.blk_last, res.blk_last) and np.array_equal(r6.gaps, res.gaps), "flat variant disagrees"
+print("gaps", res.gaps.shape, "variants agree (1, 2, 6)")
 L = _lib.lib()
 rs = dr.c_struct()
 mb = torch.empty(dr.n, dtype=torch.int32, device="cuda"); qi = torch.empty_like(mb); b0 = torch.empty_like(mb); b1 = torch.empty_like(mb)
 gaps = torch.empty((1 << 20, 4), dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
 ms = C.c_float(0)
 for it in range(12):
-    L.coral_set_scan_variant(1 + it % 4)
+    L.coral_set_scan_variant(1 + it % 6)
     _lib.check(L.coral_time_cigar_scan(C.byref(rs), 600, 20, mb.data_ptr(), qi.data_ptr(), b0.data_ptr(), b1.data_ptr(), gaps.data_ptr(), cnt.data_ptr(), 1 << 20, 10, C.byref(ms), dr.stream()), "time")
     B = dr.algorithmic_bytes()
-    print("variant %d" % (1 + it % 4), "scan %.3f ms/launch  alg bytes %.3f GB  -> %.1f GB/s (%.1f%% of 8 TB/s)" % (ms.value, B / 1e9, B / ms.value / 1e6, B / ms.value / 1e6 / 80), flush=True)
+    print("variant %d" % (1 + it % 6), "scan %.3f ms/launch  alg bytes %.3f GB  -> %.1f GB/s (%.1f%% of 8 TB/s)" % (ms.value, B / 1e9, B / ms.value / 1e6, B / ms.value / 1e6 / 80), flush=True)
 
 scr = torch.zeros(4, dtype=torch.int32, device="cuda")
-for it in range(3):
+for it in range(4):
+    L.coral_set_probe_mode(1 + it % 2)
+    print("probe mode %d:" % (1 + it % 2), end=" ")
     _lib.check(L.coral_time_stream_read(dr.cigar.data_ptr(), dr.cigar.numel(), scr.data_ptr(), 10, C.byref(ms), dr.stream()), "stream")
+    L.coral_set_scan_variant(2)
     print("plain streaming read %.3f ms  -> %.1f GB/s" % (ms.value, dr.cigar.numel() * 4 / ms.value / 1e6), flush=True)
