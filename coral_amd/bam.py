@@ -86,7 +86,7 @@ def _bgzf_blocks(data: bytes, level: int = 1):
     yield bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")      # BGZF EOF marker
 
 
-def write_bam(rec: Records, path: str, seed: int = 0, long_cigar_as_cg: bool = True) -> None:
+def write_bam(rec: Records, path: str, seed: int = 0, long_cigar_as_cg: bool = True, fast_seq: bool = False) -> None:
     """Serialise ``rec`` as a coordinate-sorted BAM (SEQ = deterministic ACGT with N at the listed non-ACGT
     positions, QUAL absent, tags NM:i and SA:Z; CIGARs with more than 65535 ops go to the CG:B,I tag)."""
     g = lambda x: x.cpu().numpy()
@@ -103,6 +103,7 @@ def write_bam(rec: Records, path: str, seed: int = 0, long_cigar_as_cg: bool = T
     out += b"BAM\x01" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(rec.header_chroms))
     for c, l in zip(rec.header_chroms, rec.header_lens):
         out += struct.pack("<i", len(c) + 1) + c.encode() + b"\0" + struct.pack("<i", l)
+    rng = np.random.default_rng(seed)
     lut = np.zeros(256, dtype=np.uint8)
     for k, v in _SEQ_CODE.items():
         lut[k] = v
@@ -113,8 +114,11 @@ def write_bam(rec: Records, path: str, seed: int = 0, long_cigar_as_cg: bool = T
         l_seq = int(qlen[i]) if has_seq[i] else 0
         seq_bytes = b""
         if l_seq:
-            k = torch.arange(l_seq, dtype=torch.int64) + i * (1 << 22)
-            s = np.frombuffer(b"ACGT", dtype=np.uint8)[(hash_u32(seed, S_SEQ, k) & 3).numpy()].copy()
+            if fast_seq:            # decode benchmarks: any ACGT content will do
+                s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, l_seq, dtype=np.uint8)]
+            else:
+                k = torch.arange(l_seq, dtype=torch.int64) + i * (1 << 22)
+                s = np.frombuffer(b"ACGT", dtype=np.uint8)[(hash_u32(seed, S_SEQ, k) & 3).numpy()].copy()
             if i in na:     # reference position -> query offset through the CIGAR
                 op, ln = ops & 15, (ops >> 4).astype(np.int64)
                 r0 = int(pos[i]) + np.cumsum(ref_adv[op] * ln) - ref_adv[op] * ln
