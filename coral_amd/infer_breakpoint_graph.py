@@ -921,8 +921,185 @@ class bam_to_breakpoint_nanopore():
             e[9] = set(self._names_of(np.union1d(rls, rrs)))
             e[8] = sum(1 for nm in self._names_of(both) if nm not in rbps) if rbps else int(len(both))
 
+    # ---- SURVEY.md §8(f) item 2 -------------------------------------------------------------------
     def compute_path_constraints(self):
-        raise NotImplementedError("path constraints belong to the cycle-decomposition step (SURVEY.md §8(f) item 2)")
+        """Reads -> subpath constraints per amplicon (ibg:1059-1323); called by the cycle step (cd:2067)."""
+        from . import path_constraints as pc
+        cutoff = self.min_bp_match_cutoff_
+        for amplicon_idx, g in enumerate(self.lr_graph):
+            store = [[], [], []]
+            self.path_constraints[amplicon_idx] = store
+            self.longest_path_constraints[amplicon_idx] = [[], [], []]
+
+            def add_path(path, label):
+                if len(path) > 5 and pc.valid_path(g, path):
+                    if path in store[0]:
+                        store[1][store[0].index(path)] += 1
+                    elif path[::-1] in store[0]:
+                        store[1][store[0].index(path[::-1])] += 1
+                    else:
+                        store[0].append(path)
+                        store[1].append(1)
+                        store[2].append(label)
+
+            # reads supporting discordant edges: [chimeric (i != j) entries, small-deletion (i == j) entries]
+            bp_reads: Dict[str, list] = {}
+            for di, bp in enumerate(g.discordant_edges):
+                for r_ in bp[10]:
+                    slot = 1 if r_[1] == r_[2] else 0
+                    bp_reads.setdefault(r_[0], [[], []])[slot].append([r_[1], r_[2], di])
+            for rn, (chim, sdel) in bp_reads.items():
+                paths = []
+                if len(chim) == 1 and not sdel:
+                    rints = [a[:4] for a in self.chimeric_alignments[rn][1]]
+                    paths.append(pc.chimeric_alignment_to_path_i(g, rints, chim[0][0], chim[0][1], chim[0][2]))
+                elif len(chim) > 1 and not sdel:
+                    chim = sorted(chim, key=lambda it: min(it[0], it[1]))
+                    if self._overlapping_query_intervals(rn, cutoff):
+                        continue
+                    for block in self._chain_blocks(chim):
+                        bps = [chim[b][2] for b in block]
+                        if len(set(bps)) < len(bps):
+                            continue
+                        rints = [a[:4] for a in self.chimeric_alignments[rn][1]]
+                        paths.append(pc.chimeric_alignment_to_path(g, rints, [chim[b][:2] for b in block], bps))
+                elif not chim and len(sdel) == 1:
+                    rints = self.large_indel_alignments[rn][0]
+                    if rints[3] < rints[4]:
+                        if not rints[2] < rints[1]:
+                            continue
+                        rints = [[rints[0], rints[3], rints[2], '+'], [rints[0], rints[1], rints[4], '+']]
+                    else:
+                        if not rints[2] > rints[1]:
+                            continue
+                        rints = [[rints[0], rints[3], rints[2], '-'], [rints[0], rints[1], rints[4], '-']]
+                    di = sdel[0][2]
+                    if rints[0][3] == '+':
+                        paths.append(pc.chimeric_alignment_to_path_i(g, rints, 1, 0, di))
+                    else:
+                        paths.append(pc.chimeric_alignment_to_path_i(g, rints, 0, 1, di))
+                elif not chim and len(sdel) > 1:
+                    gaps = self.large_indel_alignments[rn]
+                    spans = set((x[0], min(x[3], x[4]), max(x[3], x[4])) for x in gaps)
+                    if len(spans) > 1 or len(gaps) <= 1:
+                        continue
+                    pieces = [[x[0], min(x[3], x[4]), max(x[3], x[4]), '+'] for x in gaps]
+                    gaps = sorted(gaps, key=lambda it: min(it[1], it[2]))
+                    for ri, x in enumerate(gaps):
+                        pieces.append([x[0], min(x[3], x[4]), max(x[3], x[4]), '+'])
+                        pieces[ri][2] = min(x[1], x[2])
+                        pieces[ri + 1][1] = max(x[1], x[2])
+                    sdel = sorted(sdel, key=lambda it: it[0])
+                    blocks, last = [[]], 0
+                    for i, it in enumerate(sdel):
+                        if i == 0 or it[0] == last + 1:
+                            blocks[-1].append(i)
+                        else:
+                            blocks.append([i])
+                        last = it[0]
+                    for block in blocks:
+                        bps = [sdel[b][2] for b in block]
+                        if len(set(bps)) < len(bps):
+                            continue
+                        paths.append(pc.chimeric_alignment_to_path(g, pieces, [[sdel[b][0], sdel[b][0] + 1] for b in block], bps))
+                else:
+                    rints = [a[:4] for a in self.chimeric_alignments[rn][1]]
+                    gaps = self.large_indel_alignments[rn]
+                    split_at = []
+                    for x in gaps:
+                        for ri, seg in enumerate(rints):
+                            if x[0] == seg[0] and min(x[1], x[2]) > min(seg[1], seg[2]) and max(x[1], x[2]) < max(seg[1], seg[2]):
+                                split_at.append(ri)
+                                break
+                        else:
+                            split_at = None
+                            break
+                    if split_at is None:
+                        continue
+                    for rsi, ri in enumerate(split_at):
+                        rints.insert(ri, rints[ri][:])
+                        x = gaps[rsi]
+                        if rints[ri][3] == '+':
+                            rints[ri][2] = min(x[1], x[2])
+                            rints[ri + 1][1] = max(x[1], x[2])
+                        else:
+                            rints[ri][2] = max(x[1], x[2])
+                            rints[ri + 1][1] = min(x[1], x[2])
+                        for it in chim:
+                            if it[0] >= ri and it[1] >= ri:
+                                it[0] += 1
+                                it[1] += 1
+                        for it in sdel:
+                            if it[0] == rsi:
+                                chim.append([ri + 1, ri, it[2]] if rints[ri][3] == '+' else [ri, ri + 1, it[2]])
+                    chim = sorted(chim, key=lambda it: min(it[0], it[1]))
+                    blocks = self._chain_blocks(chim)
+                    if self._overlapping_query_intervals(rn, cutoff):
+                        continue
+                    for block in blocks:
+                        bps = [chim[b][2] for b in block]
+                        if len(set(bps)) < len(bps):
+                            continue
+                        paths.append(pc.chimeric_alignment_to_path(g, rints, [chim[b][:2] for b in block], bps))
+                for path in paths:
+                    add_path(path, amplicon_idx)
+            logging.debug(_t() + "There are %d distinct subpaths due to reads involving breakpoints in amplicon %d."
+                          % (len(store[0]), amplicon_idx + 1))
+
+            # reads without breakpoints: every alignment record of the amplicon's intervals (ibg:1296-1321)
+            concordant = set()
+            for ce in g.concordant_edges:
+                for rn in ce[9]:
+                    if rn not in self.large_indel_alignments and rn not in self.chimeric_alignments:
+                        concordant.add(rn)
+            if concordant:
+                dr = self.rec
+                name_to_id = self._name_ids()
+                ids = np.fromiter((name_to_id[rn] for rn in concordant), dtype=np.int64, count=len(concordant))
+                is_conc = np.zeros(dr.n_names, dtype=bool)
+                is_conc[ids] = True
+                for aint in self.amplicon_intervals:
+                    if amplicon_idx != self.ccid2id[aint[3]] - 1:
+                        continue
+                    recs = dr.region(self._tid_of[aint[0]], aint[1], aint[2] + 1)
+                    recs = recs[(dr.h_mapq[recs] >= 20) & is_conc[dr.h_name_id[recs]]]
+                    if not len(recs):
+                        continue
+                    start, end = dr.h_pos[recs].astype(np.int64), dr.h_end[recs].astype(np.int64)
+                    lo, hi, order = pc.classify_alignments(g, aint[0], start, end)
+                    keep = lo <= hi
+                    code = lo[keep] * (len(order) + 1) + hi[keep]
+                    u, first, cnt = np.unique(code, return_index=True, return_counts=True)
+                    for k in np.argsort(first, kind="stable"):          # first appearance in fetch order
+                        a = g.sequence_edges[order[int(u[k]) // (len(order) + 1)]]
+                        b = g.sequence_edges[order[int(u[k]) % (len(order) + 1)]]
+                        path = pc.traverse_through_sequence_edge(g, (a[0], a[1], '-'), (b[0], b[2], '+'))[1:-1]
+                        for _ in range(int(cnt[k])):
+                            add_path(path, amplicon_idx)
+            logging.debug(_t() + "There are %d distinct subpaths in total in amplicon %d." % (len(store[0]), amplicon_idx + 1))
+
+    def _name_ids(self):
+        if getattr(self, "_name_to_id", None) is None:
+            self._name_to_id = {nm: k for k, nm in enumerate(self.rec.names)}
+        return self._name_to_id
+
+    @staticmethod
+    def _chain_blocks(entries):
+        """Consecutive (i, j) entries that share an alignment index form one block (ibg:1102-1109)."""
+        blocks = [[0]]
+        last = max(entries[0][0], entries[0][1])
+        for i in range(1, len(entries)):
+            if min(entries[i][0], entries[i][1]) == last:
+                blocks[-1].append(i)
+            else:
+                blocks.append([i])
+            last = max(entries[i][0], entries[i][1])
+        return blocks
+
+    def _overlapping_query_intervals(self, rn, cutoff):
+        """True when two consecutive local alignments of the read overlap by more than ``cutoff`` on the read (ibg:1112-1117)."""
+        qints = self.chimeric_alignments[rn][0]
+        return any(qints[k + 1][0] - qints[k][1] < -cutoff for k in range(len(qints) - 1))
 
     def closebam(self):
         self.lr_bamfh.close()

@@ -154,6 +154,10 @@ def main():
             bg.output_breakpoint_graph_lr(b.lr_graph[gi], fn)
             files[os.path.basename(fn)] = open(fn).read()
     snap["files"] = files
+    if not a.output_bp:
+        # the step right after the graph build (ibg:1059-1323, called from cd:2067)
+        b.compute_path_constraints()
+        snap["F2"] = dict(path_constraints=_js(b.path_constraints))
     with open(a.out_json, "w") as fp:
         json.dump(snap, fp, indent=None, separators=(",", ":"))
     for k, v in files.items():

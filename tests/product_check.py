@@ -120,6 +120,9 @@ def check_product_against_golden(case, golden_dir, tmp_path, device):
         assert sorted(files) == sorted(gold["files"])
         for k in files:
             compare_graph_text(files[k], gold["files"][k])
+        if "F2" in gold:                  # path constraints of the cycle step
+            b.compute_path_constraints()
+            assert canon(b.path_constraints) == gold["F2"]["path_constraints"]
     else:
         got = sorted(l.split("\t")[0:3:2] for g in b.lr_graph for l in graph_text(g).splitlines() if l.startswith("disc"))
         exp = sorted(l.split("\t")[0:3:2] for t in gold["files"].values() for l in t.splitlines() if l.startswith("disc"))
