@@ -110,7 +110,8 @@ def main():
                                    "cycle step skipped" % (cfg.name, cfg.n_reads, cfg.mean_len, len(cfg.seeds), len(cfg.windows)),
                        "records": int(dr.n_total), "cigar_ops": int(dr.total_ops_all), "amplicons": len(b.lr_graph),
                        "discordant_edges": sum(len(g.discordant_edges) for g in b.lr_graph),
-                       "generate_s": round(gen_s, 2), "parallelism": "records sharded over %d GPU(s)" % world},
+                       "generate_s": round(gen_s, 2), "parallelism": "records sharded over %d GPU(s)" % world,
+                       "phase_ms_last_step": {k: round(v * 1e3, 1) for k, v in ibg.PHASE_SECONDS.items()}},
             "roofline": {"bound": "hbm", "kernel": "k_cigar_scan_v2<8>", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": pmc_traffic(cfg, world), "launch_ms": scan_ms_avg,
                          "algorithmic_bytes_per_launch": int(alg_bytes_local)},

@@ -1165,26 +1165,40 @@ class _SegIndexView:
         return c in o._tid_of and o._tid_of[c] in o._seg_tids
 
 
+PHASE_SECONDS: Dict[str, float] = {}      # wall time of every phase of the last build (same phases the reference logs)
+
+
 def build_graph_from_records(records, seedfile, cn_seg, output_prefix=None, min_bp_support=1.0, output_bp=False,
                              graph_class=BreakpointGraph):
     """The call sequence of reconstruct_graph (ibg:1349-1394) on already-decoded records."""
+    clock = time.perf_counter
+    t0 = clock()
+
+    def lap(name, msg):
+        nonlocal t0
+        t1 = clock()
+        PHASE_SECONDS[name] = t1 - t0
+        t0 = t1
+        logging.info(_t() + msg)
+
+    PHASE_SECONDS.clear()
     b2bn = bam_to_breakpoint_nanopore(None, seedfile, records=records)
     b2bn.min_bp_cov_factor = min_bp_support
-    logging.info(_t() + "Opened LR bam files.")
+    lap("open", "Opened LR bam files.")
     b2bn.read_cns(cn_seg)
-    logging.info(_t() + "Completed parsing CN segment files.")
+    lap("read_cns", "Completed parsing CN segment files.")
     b2bn.fetch()
-    logging.info(_t() + "Completed fetching reads containing breakpoints.")
+    lap("fetch", "Completed fetching reads containing breakpoints.")
     b2bn.hash_alignment_to_seg()
-    logging.info(_t() + "Completed hashing chimeric reads to CN segments.")
+    lap("hash_alignment_to_seg", "Completed hashing chimeric reads to CN segments.")
     b2bn.find_amplicon_intervals()
-    logging.info(_t() + "Completed finding amplicon intervals.")
+    lap("find_amplicon_intervals", "Completed finding amplicon intervals.")
     b2bn.find_smalldel_breakpoints()
-    logging.info(_t() + "Completed finding small del breakpoints.")
+    lap("find_smalldel_breakpoints", "Completed finding small del breakpoints.")
     b2bn.find_breakpoints()
-    logging.info(_t() + "Completed finding all discordant breakpoints.")
+    lap("find_breakpoints", "Completed finding all discordant breakpoints.")
     b2bn.build_graph(graph_class)
-    logging.info(_t() + "Breakpoint graph built for all amplicons.")
+    lap("build_graph", "Breakpoint graph built for all amplicons.")
     if output_bp:
         for gi in range(len(b2bn.lr_graph)):
             bp_stats_i = []
@@ -1196,17 +1210,17 @@ def build_graph_from_records(records, seedfile, cn_seg, output_prefix=None, min_
             if output_prefix is not None:
                 output_breakpoint_info_lr(b2bn.lr_graph[gi], output_prefix + "_amplicon" + str(gi + 1) + "_breakpoints.txt",
                                           bp_stats_i)
-        logging.info(_t() + "Wrote breakpoint information, for all amplicons, to %s." % (str(output_prefix) + '_amplicon*_breakpoints.txt'))
+        lap("output", "Wrote breakpoint information, for all amplicons, to %s." % (str(output_prefix) + '_amplicon*_breakpoints.txt'))
     else:
         b2bn.assign_cov()
-        logging.info(_t() + "Fetched read coverage for all sequence and concordant edges.")
+        lap("assign_cov", "Fetched read coverage for all sequence and concordant edges.")
         for g in b2bn.lr_graph:
             compute_cn_lr(g, b2bn.normal_cov)
-        logging.info(_t() + "Computed CN for all edges.")
+        lap("compute_cn_lr", "Computed CN for all edges.")
         if output_prefix is not None:
             for gi in range(len(b2bn.lr_graph)):
                 output_breakpoint_graph_lr(b2bn.lr_graph[gi], output_prefix + "_amplicon" + str(gi + 1) + "_graph.txt")
-        logging.info(_t() + "Wrote breakpoint graph for all complicons to %s." % (str(output_prefix) + '_amplicon*_graph.txt'))
+        lap("output", "Wrote breakpoint graph for all complicons to %s." % (str(output_prefix) + '_amplicon*_graph.txt'))
     return b2bn
 
 

@@ -30,15 +30,17 @@ def test_strict_order_in_seeded_subprocess():
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
 
 
-def test_gpu_matches_oracle_cfg1_subsample(tmp_path):
-    """Product (HIP kernels) vs CPU oracle on 12k reads of config 1: every line of every graph file; CN to 1e-6."""
+@pytest.mark.parametrize("config,n_reads", [("cfg1", 12000), ("cfg2", 10000), ("cfg5", 1500)])
+def test_gpu_matches_oracle_subsample(config, n_reads, tmp_path):
+    """Product (HIP kernels) vs CPU oracle on a seeded subsample of BASELINE.json configs 1, 2 and 5 (ultra-long reads,
+    ~10^4 CIGAR ops per record): every integer of every edge; graph text with CN to 1e-6 under PYTHONHASHSEED=0."""
     from coral_amd import infer_breakpoint_graph as ibg
     from coral_amd.breakpoint_graph import graph_text
     from coral_amd.records import DeviceRecords
     from oracle import coral_oracle as O
     from oracle.hostrecords import HostRecords
     from tests.product_check import compare_graph_text
-    cfg = synth.scaled_config("cfg1", 12000)
+    cfg = synth.scaled_config(config, n_reads)
     rec = synth.generate(cfg, "cpu")
     cn = str(tmp_path / "cn.bed"); seeds = str(tmp_path / "seeds.bed")
     synth.write_cn_bed(cfg, cn); synth.write_seed_bed(cfg, seeds)

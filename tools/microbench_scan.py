@@ -40,3 +40,15 @@ for it in range(4):
     _lib.check(L.coral_time_stream_read(dr.cigar.data_ptr(), dr.cigar.numel(), scr.data_ptr(), 10, C.byref(ms), dr.stream()), "stream")
     L.coral_set_scan_variant(2)
     print("plain streaming read %.3f ms  -> %.1f GB/s" % (ms.value, dr.cigar.numel() * 4 / ms.value / 1e6), flush=True)
+
+import time as _t
+L.coral_set_scan_variant(3)
+for idle in (0.0, 0.2, 1.0, 1.0):
+    _t.sleep(idle)
+    _lib.check(L.coral_time_cigar_scan(C.byref(rs), 600, 20, mb.data_ptr(), qi.data_ptr(), b0.data_ptr(), b1.data_ptr(), gaps.data_ptr(), cnt.data_ptr(), 1 << 20, 1, C.byref(ms), dr.stream()), "time")
+    print("single launch after %.1fs idle: %.3f ms -> %.1f GB/s" % (idle, ms.value, B / ms.value / 1e6), flush=True)
+for idle in (1.0, 1.0):
+    _t.sleep(idle)
+    scr2 = torch.zeros(1 << 24, device="cuda"); scr2.add_(1.0); scr2.add_(1.0)      # ~0.1 ms of unrelated GPU work right before
+    _lib.check(L.coral_time_cigar_scan(C.byref(rs), 600, 20, mb.data_ptr(), qi.data_ptr(), b0.data_ptr(), b1.data_ptr(), gaps.data_ptr(), cnt.data_ptr(), 1 << 20, 1, C.byref(ms), dr.stream()), "time")
+    print("single launch after %.1fs idle + small torch op: %.3f ms -> %.1f GB/s" % (idle, ms.value, B / ms.value / 1e6), flush=True)
