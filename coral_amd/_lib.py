@@ -18,6 +18,11 @@ class coral_records_t(C.Structure):
                 ("flagmq", C.c_void_p), ("n_cigar", C.c_void_p), ("cigar_off", C.c_void_p), ("cigar", C.c_void_p)]
 
 
+class coral_chimeric_t(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("off", C.c_void_p), ("qs", C.c_void_p), ("qe", C.c_void_p), ("tid", C.c_void_p),
+                ("ra", C.c_void_p), ("rb", C.c_void_p), ("strand", C.c_void_p), ("mapq", C.c_void_p)]
+
+
 _lib = None
 
 def lib():
@@ -48,6 +53,9 @@ def lib():
     L.coral_time_stream_read.restype = C.c_int
     L.coral_first_seen_rows.argtypes = [C.c_int64, C.c_int32, P, P]
     L.coral_first_seen_rows.restype = C.c_int
+    L.coral_bp_candidates.argtypes = [C.POINTER(coral_chimeric_t), C.c_int32, P, C.c_int32, C.c_int32, P, P, P, P, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, C.c_int32, C.POINTER(C.c_int32), P]
+    L.coral_bp_candidates.restype = C.c_int
     L.coral_cluster_first_fit.argtypes = [C.c_int64, P, P, C.c_int64, P, C.POINTER(C.c_int32)]
     L.coral_cluster_first_fit.restype = C.c_int
     L.coral_bam_decode_open.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]

@@ -40,6 +40,14 @@ class ChimericTable:
     def n_reads(self):
         return len(self.name_id)
 
+    def device_arrays(self, device):
+        """int32 device copies of (off, qs, qe, tid, ra, rb, strand, mapq), uploaded once per table."""
+        import torch
+        if getattr(self, "_dev", None) is None or self._dev[0] != str(device):
+            up = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.int32))).to(device)
+            self._dev = (str(device), [up(x) for x in (self.off, self.qs, self.qe, self.tid, self.ra, self.rb, self.strand, self.mapq)])
+        return self._dev[1]
+
     @property
     def n_rows(self):
         return len(self.qs)
@@ -201,65 +209,12 @@ class Candidates:
         return Candidates(**{k: np.concatenate([getattr(p, k) for p in parts]) for k in Candidates.FIELDS})
 
 
-def _interval2bp(T: ChimericTable, a, b, ia, ib, gap, chr_rank) -> Candidates:
-    """bu:289-295 for row pairs (a = R1, b = R2); orientation 0 '+', 1 '-'."""
-    c1r, c2r = chr_rank[T.tid[a]], chr_rank[T.tid[b]]
-    if (c1r < 0).any() or (c2r < 0).any():
-        raise KeyError("contig name outside chr1..22,X,Y,M")                       # gn:13-18 lookup at bu:293
-    first_form = (c2r < c1r) | ((c2r == c1r) & (T.ra[b] < T.rb[a]))
-    f = first_form
-    return Candidates(
-        c1=np.where(f, T.tid[a], T.tid[b]), p1=np.where(f, T.rb[a], T.ra[b]),
-        o1=np.where(f, T.strand[a], 1 - T.strand[b]),
-        c2=np.where(f, T.tid[b], T.tid[a]), p2=np.where(f, T.ra[b], T.rb[a]),
-        o2=np.where(f, 1 - T.strand[b], T.strand[a]),
-        read=T.read[a], i=np.where(f, ia, ib), j=np.where(f, ib, ia), gap=gap, swapped=np.where(f, 0, 1),
-        mqa=T.mapq[a], mqb=T.mapq[b])
-
-
-def _pairs_of_reads(T: ChimericTable, reads: np.ndarray):
-    """Row indices (a, b) of consecutive segments and (a, mid, b) of skip-one triples for ``reads`` in order."""
-    cnt = T.off[reads + 1] - T.off[reads]
-    n_adj = np.maximum(cnt - 1, 0)
-    own = np.repeat(np.arange(len(reads)), n_adj)
-    k = np.arange(len(own)) - np.repeat(np.cumsum(n_adj) - n_adj, n_adj)
-    a = T.off[reads][own] + k
-    n_tri = np.maximum(cnt - 2, 0)
-    own3 = np.repeat(np.arange(len(reads)), n_tri)
-    k3 = np.arange(len(own3)) - np.repeat(np.cumsum(n_tri) - n_tri, n_tri) + 1
-    mid = T.off[reads][own3] + k3
-    return own, k, a, a + 1, own3, k3, mid
-
-
-def _merge_in_read_order(own, first: Candidates, own3, second: Candidates) -> Candidates:
-    """Per read: all consecutive-pair candidates, then all skip-one candidates (bu:78-95), reads in given order."""
-    if not len(second):
-        return first
-    key = np.concatenate([own * 2, own3 * 2 + 1])
-    order = np.argsort(key, kind="stable")
-    return Candidates.concat([first, second]).take(order)
-
-
-def candidates_between(T: ChimericTable, reads: np.ndarray, I1, I2, chr_rank, min_bp_match_cutoff=100, min_mapq=20,
+def candidates_between(T: ChimericTable, reads: np.ndarray, I1, I2, chr_rank, dr, min_bp_match_cutoff=100, min_mapq=20,
                        gap_mapq=10) -> Candidates:
     """alignment2bp (bu:70-96) for ``reads`` (indices into T, in iteration order) between intervals I1 and I2
-    (each (tid, start, end))."""
-    own, k, a, b, own3, k3, mid = _pairs_of_reads(T, reads)
-    gap = T.qs[b] - T.qe[a]
-    o1a, o2a = rows_overlap(T, a, *I1), rows_overlap(T, a, *I2)
-    o1b, o2b = rows_overlap(T, b, *I1), rows_overlap(T, b, *I2)
-    hit = (gap + min_bp_match_cutoff >= 0) & (T.mapq[a] >= min_mapq) & (T.mapq[b] >= min_mapq) & \
-          ((o1a & o2b) | (o1b & o2a))
-    used = np.zeros(len(T.qs) + 1, dtype=bool)        # used[row a] <=> bassigned[k] of that read
-    used[a[hit]] = True
-    first = _interval2bp(T, a[hit], b[hit], k[hit], k[hit] + 1, gap[hit], chr_rank)
-    lo, hi = mid - 1, mid + 1
-    o1l, o2l = rows_overlap(T, lo, *I1), rows_overlap(T, lo, *I2)
-    o1h, o2h = rows_overlap(T, hi, *I1), rows_overlap(T, hi, *I2)
-    hit3 = ~used[lo] & ~used[mid] & (T.mapq[mid] < gap_mapq) & (T.mapq[lo] >= min_mapq) & (T.mapq[hi] >= min_mapq) & \
-           ((o1l & o2h) | (o1h & o2l))
-    second = _interval2bp(T, lo[hit3], hi[hit3], k3[hit3] - 1, k3[hit3] + 1, T.qs[hi[hit3]] - T.qe[lo[hit3]], chr_rank)
-    return _merge_in_read_order(own[hit], first, own3[hit3], second)
+    (each (tid, start, end)) — coral_bp_candidates, mode 1."""
+    from . import kernels
+    return kernels.bp_candidates(dr, T, reads, 1, [I1, I2], chr_rank, min_bp_match_cutoff, min_mapq, 100, gap_mapq)
 
 
 def first_interval_overlap(T: ChimericTable, intervals: Sequence[Tuple[int, int, int]]) -> np.ndarray:
@@ -272,27 +227,8 @@ def first_interval_overlap(T: ChimericTable, intervals: Sequence[Tuple[int, int,
     return io
 
 
-def _discordant_pair(T: ChimericTable, a, b, gap_):
-    """bu:146-161: opposite strands, or |query gap - reference gap| > max(gap_, |0.2 * query gap|)."""
-    gr = T.qs[b] - T.qe[a]
-    grr = np.where(T.strand[b] == 0, T.ra[b] - T.rb[a], T.rb[a] - T.ra[b])
-    return (T.strand[a] != T.strand[b]) | (np.abs(gr - grr) > np.maximum(float(gap_), np.abs(gr * 0.2)))
-
-
-def candidates_within(T: ChimericTable, intervals, chr_rank, min_bp_match_cutoff=100, min_mapq=20, gap_=100,
+def candidates_within(T: ChimericTable, intervals, chr_rank, dr, min_bp_match_cutoff=100, min_mapq=20, gap_=100,
                       gap_mapq=10) -> Candidates:
-    """alignment2bp_l (bu:129-186) for every chimeric read in dict order."""
-    reads = np.nonzero(~T.failed)[0]
-    io = first_interval_overlap(T, intervals)
-    own, k, a, b, own3, k3, mid = _pairs_of_reads(T, reads)
-    gap = T.qs[b] - T.qe[a]
-    hit = (gap + min_bp_match_cutoff >= 0) & (io[a] >= 0) & (io[b] >= 0) & (io[a] == io[b]) & \
-          _discordant_pair(T, a, b, gap_) & (T.mapq[a] >= min_mapq) & (T.mapq[b] >= min_mapq)
-    used = np.zeros(len(T.qs) + 1, dtype=bool)
-    used[a[hit]] = True
-    first = _interval2bp(T, a[hit], b[hit], k[hit], k[hit] + 1, gap[hit], chr_rank)
-    lo, hi = mid - 1, mid + 1
-    hit3 = ~used[lo] & ~used[mid] & (T.mapq[mid] < gap_mapq) & (T.mapq[lo] >= min_mapq) & (T.mapq[hi] >= min_mapq) & \
-           (io[lo] >= 0) & (io[hi] >= 0) & (io[lo] == io[hi]) & _discordant_pair(T, lo, hi, gap_)
-    second = _interval2bp(T, lo[hit3], hi[hit3], k3[hit3] - 1, k3[hit3] + 1, T.qs[hi[hit3]] - T.qe[lo[hit3]], chr_rank)
-    return _merge_in_read_order(own[hit], first, own3[hit3], second)
+    """alignment2bp_l (bu:129-186) for every chimeric read in dict order — coral_bp_candidates, mode 0."""
+    from . import kernels
+    return kernels.bp_candidates(dr, T, None, 0, list(intervals), chr_rank, min_bp_match_cutoff, min_mapq, gap_, gap_mapq)

@@ -951,3 +951,166 @@ extern "C" int coral_read_counter(const uint32_t *dev_counter, uint32_t *host_va
     if (e != hipSuccess) return hip_err(e, "read_counter sync");
     return CORAL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// K4  breakpoint candidates from chimeric alignments (one thread per read, two passes: count -> scan -> write, so the
+//     output order is exactly the reference's: reads in the given order, per read all consecutive-pair candidates then
+//     all skip-one candidates).
+//     mode 0 = alignment2bp_l (/root/reference/src/breakpoint_utilities.py:129-186): both segments in the SAME interval
+//     mode 1 = alignment2bp   (bu:70-96): the two segments fall in the two given intervals, in either order
+//     interval2bp (bu:289-295) canonicalises every candidate.
+// ---------------------------------------------------------------------------------------------
+struct CandParams {
+    int n_sel;
+    const int32_t *sel;
+    const int32_t *off, *qs, *qe, *tid, *ra, *rb, *strand, *mapq;
+    int mode, n_int;
+    const int32_t *int_tid, *int_start, *int_end;
+    const int32_t *chr_rank;
+    int n_tid;
+    int cutoff, min_mapq, gap_, gap_mapq;
+};
+
+__device__ __forceinline__ bool row_overlaps(const CandParams &P, int row, int t, int s, int e) {
+    // interval_overlap(rint, [chr, s, e]) with rint = [chr, ra, rb]: for '-' rows ra > rb (bu:11-15, Appendix A Q1)
+    return P.tid[row] == t && P.ra[row] <= e && s <= P.rb[row];
+}
+
+__device__ __forceinline__ int first_interval(const CandParams &P, int row) {
+    for (int k = 0; k < P.n_int; ++k)
+        if (row_overlaps(P, row, P.int_tid[k], P.int_start[k], P.int_end[k])) return k;
+    return -1;
+}
+
+__device__ __forceinline__ bool pair_qualifies(const CandParams &P, int a, int b) {
+    if (P.mode == 1) {
+        const bool a1 = row_overlaps(P, a, P.int_tid[0], P.int_start[0], P.int_end[0]);
+        const bool a2 = row_overlaps(P, a, P.int_tid[1], P.int_start[1], P.int_end[1]);
+        const bool b1 = row_overlaps(P, b, P.int_tid[0], P.int_start[0], P.int_end[0]);
+        const bool b2 = row_overlaps(P, b, P.int_tid[1], P.int_start[1], P.int_end[1]);
+        return (a1 && b2) || (b1 && a2);
+    }
+    const int ia = first_interval(P, a), ib = first_interval(P, b);
+    if (ia < 0 || ib < 0 || ia != ib) return false;
+    if (P.strand[a] != P.strand[b]) return true;
+    const int gr = P.qs[b] - P.qe[a];
+    const int grr = (P.strand[b] == 0) ? (P.ra[b] - P.rb[a]) : (P.rb[a] - P.ra[b]);
+    const long long d = (long long)gr - (long long)grr;
+    const double lim = fmax((double)P.gap_, fabs((double)gr * 0.2));
+    return (double)(d < 0 ? -d : d) > lim;
+}
+
+__device__ __forceinline__ void emit_candidate(const CandParams &P, int a, int b, int ia, int ib, int read, int32_t *__restrict__ out,
+                                               int32_t *__restrict__ err) {
+    const int c1r = P.chr_rank[P.tid[a]], c2r = P.chr_rank[P.tid[b]];
+    if (c1r < 0 || c2r < 0) *err = 1;                                   // contig outside chr1..22,X,Y,M (KeyError in the reference)
+    const bool first_form = (c2r < c1r) || (c2r == c1r && P.ra[b] < P.rb[a]);
+    const int gap = P.qs[b] - P.qe[a];
+    if (first_form) {
+        out[0] = P.tid[a]; out[1] = P.rb[a]; out[2] = P.strand[a];
+        out[3] = P.tid[b]; out[4] = P.ra[b]; out[5] = 1 - P.strand[b];
+        out[7] = ia; out[8] = ib; out[10] = 0;
+    } else {
+        out[0] = P.tid[b]; out[1] = P.ra[b]; out[2] = 1 - P.strand[b];
+        out[3] = P.tid[a]; out[4] = P.rb[a]; out[5] = P.strand[a];
+        out[7] = ib; out[8] = ia; out[10] = 1;
+    }
+    out[6] = read; out[9] = gap; out[11] = P.mapq[a]; out[12] = P.mapq[b];
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_bp_candidates(CandParams P, int32_t *__restrict__ counts, int32_t *__restrict__ cand, int cap) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.n_sel) return;
+    const int read = P.sel ? P.sel[i] : i;
+    const int base = P.off[read], n = P.off[read + 1] - base;
+    int32_t *err = counts + P.n_sel + 1;
+    if (n > 64) { *err = 2; if (!WRITE) counts[i] = 0; return; }
+    int w = WRITE ? counts[i] : 0;          // write cursor (exclusive prefix) / running count
+    unsigned long long used = 0ull;
+    for (int k = 0; k + 1 < n; ++k) {
+        const int a = base + k, b = a + 1;
+        const int gap = P.qs[b] - P.qe[a];
+        if (gap + P.cutoff >= 0 && P.mapq[a] >= P.min_mapq && P.mapq[b] >= P.min_mapq && pair_qualifies(P, a, b)) {
+            used |= 1ull << k;
+            if (WRITE) { if (w < cap) emit_candidate(P, a, b, k, k + 1, read, cand + (long long)w * 13, err); }
+            ++w;
+        }
+    }
+    for (int k = 1; k + 1 < n; ++k) {
+        const int a = base + k - 1, m = base + k, b = base + k + 1;
+        if (((used >> (k - 1)) & 1ull) || ((used >> k) & 1ull)) continue;
+        if (!(P.mapq[m] < P.gap_mapq && P.mapq[a] >= P.min_mapq && P.mapq[b] >= P.min_mapq)) continue;
+        if (pair_qualifies(P, a, b)) {
+            if (WRITE) { if (w < cap) emit_candidate(P, a, b, k - 1, k + 1, read, cand + (long long)w * 13, err); }
+            ++w;
+        }
+    }
+    if (!WRITE) counts[i] = w;
+}
+
+// exclusive prefix sum of counts[0..n) in place, total into counts[n]; one workgroup (n is the number of chimeric reads)
+__global__ __launch_bounds__(1024) void k_exclusive_scan_i32(int32_t *__restrict__ v, int n) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int a = min(n, t * per), b = min(n, a + per);
+    int s = 0;
+    for (int i = a; i < b; ++i) s += v[i];
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int x = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int i = a; i < b; ++i) {
+        const int x = v[i];
+        v[i] = run;
+        run += x;
+    }
+    if (t == 1023) v[n] = part[1023];
+}
+
+extern "C" int coral_bp_candidates(const coral_chimeric_t *ct, int32_t n_sel, const int32_t *sel, int32_t mode, int32_t n_int,
+                                   const int32_t *int_tid, const int32_t *int_start, const int32_t *int_end,
+                                   const int32_t *chr_rank, int32_t n_tid, int32_t min_bp_match_cutoff, int32_t min_mapq,
+                                   int32_t gap_, int32_t gap_mapq, int32_t *counts, int32_t *cand, int32_t cap,
+                                   int32_t *n_out, void *stream) {
+    if (!ct || !n_out || n_sel < 0) return set_err(CORAL_ERR_ARG, "bp_candidates: bad arguments");
+    *n_out = 0;
+    if (n_sel == 0) return CORAL_OK;
+    if (!ct->off || !ct->qs || !ct->qe || !ct->tid || !ct->ra || !ct->rb || !ct->strand || !ct->mapq || !counts || !chr_rank ||
+        !int_tid || !int_start || !int_end || (cap > 0 && !cand))
+        return set_err(CORAL_ERR_ARG, "bp_candidates: null argument");
+    if (mode == 1 && n_int != 2) return set_err(CORAL_ERR_ARG, "bp_candidates: mode 1 needs exactly two intervals");
+    if (!sel && n_sel != ct->n_reads) return set_err(CORAL_ERR_ARG, "bp_candidates: sel == NULL means all reads");
+    CandParams P;
+    P.n_sel = n_sel; P.sel = sel;
+    P.off = ct->off; P.qs = ct->qs; P.qe = ct->qe; P.tid = ct->tid; P.ra = ct->ra; P.rb = ct->rb; P.strand = ct->strand; P.mapq = ct->mapq;
+    P.mode = mode; P.n_int = n_int; P.int_tid = int_tid; P.int_start = int_start; P.int_end = int_end;
+    P.chr_rank = chr_rank; P.n_tid = n_tid;
+    P.cutoff = min_bp_match_cutoff; P.min_mapq = min_mapq; P.gap_ = gap_; P.gap_mapq = gap_mapq;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(counts + n_sel, 0, 2 * sizeof(int32_t), s);
+    if (e != hipSuccess) return hip_err(e, "bp_candidates memset");
+    const int blocks = (n_sel + 255) / 256;
+    hipLaunchKernelGGL(k_bp_candidates<false>, dim3(blocks), dim3(256), 0, s, P, counts, cand, (int)cap);
+    hipLaunchKernelGGL(k_exclusive_scan_i32, dim3(1), dim3(1024), 0, s, counts, (int)n_sel);
+    int32_t tail[2] = {0, 0};
+    e = hipMemcpyAsync(tail, counts + n_sel, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return hip_err(e, "bp_candidates count");
+    *n_out = tail[0];
+    if (tail[1] == 2) return set_err(CORAL_ERR_ARG, "bp_candidates: a read has more than 64 local alignments");
+    if (tail[0] > cap) return set_err(CORAL_ERR_CAPACITY, "bp_candidates: candidate buffer too small");
+    if (tail[0] == 0) return CORAL_OK;
+    hipLaunchKernelGGL(k_bp_candidates<true>, dim3(blocks), dim3(256), 0, s, P, counts, cand, (int)cap);
+    e = hipMemcpyAsync(tail, counts + n_sel, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return hip_err(e, "bp_candidates write");
+    if (tail[1] == 1) return set_err(CORAL_ERR_FORMAT, "bp_candidates: contig outside chr1..22,X,Y,M");
+    return CORAL_OK;
+}

@@ -602,7 +602,7 @@ class bam_to_breakpoint_nanopore():
                     here = self.amplicon_intervals[cur]
                     reads = np.fromiter(map(self._chim_index.__getitem__, grp_names), dtype=np.int64, count=len(grp_names))   # set order (Q21)
                     cands = candidates_between(T, reads, (self._tid_of[c], ns, ne),
-                                               (self._tid_of[here[0]], here[1], here[2]), self._chr_rank,
+                                               (self._tid_of[here[0]], here[1], here[2]), self._chr_rank, self.rec,
                                                self.min_bp_match_cutoff_, 20)
                     cands.read = T.name_id[cands.read]
                     logging.debug(_t() + "\t\tFound %d reads connecting the two intervals." % len(cands))
@@ -819,7 +819,7 @@ class bam_to_breakpoint_nanopore():
         """Breakpoints from chimeric alignments inside the amplicon intervals (ibg:676-718)."""
         T = self._chim
         ivs = [(self._tid_of[iv[0]], iv[1], iv[2]) for iv in self.amplicon_intervals]
-        cands = candidates_within(T, ivs, self._chr_rank, self.min_bp_match_cutoff_, 20, 100)
+        cands = candidates_within(T, ivs, self._chr_rank, self.rec, self.min_bp_match_cutoff_, 20, 100)
         cands.read = T.name_id[cands.read]
         logging.debug(_t() + "Found %d reads with new breakpoints." % (len(cands)))
         self._add_clustered(cands)

@@ -184,3 +184,44 @@ def point_cover(dr, points: Sequence[Tuple[int, int]], pair_cap: int = 1 << 20, 
     bounds = np.searchsorted(pt, np.arange(len(uniq) + 1))
     per_uniq = [rec[bounds[j]:bounds[j + 1]] for j in range(len(uniq))]
     return [per_uniq[j] for j in inverse.reshape(-1)]
+
+
+def _bp_candidates_local(dr, T, sel, mode: int, intervals, chr_rank, cutoff: int, min_mapq: int, gap_: int, gap_mapq: int) -> np.ndarray:
+    """int32 [K, 13] candidate rows from coral_bp_candidates (runs on this process's GPU; the chimeric table is small and
+    lives with the host logic, so this step is not sharded)."""
+    from .chimeric import ChimericTable  # noqa: F401
+    L = _lib.lib()
+    dev = dr.device
+    n_sel = T.n_reads if sel is None else len(sel)
+    if n_sel == 0 or T.n_rows == 0:
+        return np.zeros((0, 13), dtype=np.int32)
+    off, qs, qe, tid, ra, rb, strand, mapq = T.device_arrays(dev)
+    ct = _lib.coral_chimeric_t(T.n_reads, off.data_ptr(), qs.data_ptr(), qe.data_ptr(), tid.data_ptr(), ra.data_ptr(),
+                               rb.data_ptr(), strand.data_ptr(), mapq.data_ptr())
+    sel_t = None if sel is None else torch.from_numpy(np.ascontiguousarray(np.asarray(sel, dtype=np.int32))).to(dev)
+    iv = np.asarray(intervals, dtype=np.int32).reshape(-1, 3)
+    it, is_, ie = (torch.from_numpy(np.ascontiguousarray(iv[:, k])).to(dev) for k in range(3))
+    cr = torch.from_numpy(np.ascontiguousarray(np.asarray(chr_rank, dtype=np.int32))).to(dev)
+    counts = torch.empty(n_sel + 2, dtype=torch.int32, device=dev)
+    cap = max(1024, 2 * n_sel)
+    while True:
+        cand = torch.empty((cap, 13), dtype=torch.int32, device=dev)
+        n_out = C.c_int32(0)
+        rc = L.coral_bp_candidates(C.byref(ct), n_sel, None if sel_t is None else sel_t.data_ptr(), mode, len(iv),
+                                   it.data_ptr(), is_.data_ptr(), ie.data_ptr(), cr.data_ptr(), len(chr_rank), cutoff,
+                                   min_mapq, gap_, gap_mapq, counts.data_ptr(), cand.data_ptr(), cap, C.byref(n_out),
+                                   dr.stream())
+        if rc == -3:                      # CORAL_ERR_CAPACITY
+            cap = int(n_out.value)
+            continue
+        if rc == -4:                      # CORAL_ERR_FORMAT: contig outside chr1..22,X,Y,M
+            raise KeyError("contig name outside chr1..22,X,Y,M")      # gn:13-18 lookup at bu:293
+        _lib.check(rc, "coral_bp_candidates")
+        return cand[:n_out.value].cpu().numpy()
+
+
+def bp_candidates(dr, T, sel, mode: int, intervals, chr_rank, cutoff=100, min_mapq=20, gap_=100, gap_mapq=10):
+    """Breakpoint candidates (coral_amd.chimeric.Candidates) of the chimeric reads ``sel`` (None = all, dict order)."""
+    from .chimeric import Candidates
+    rows = _bp_candidates_local(dr, T, sel, mode, intervals, chr_rank, cutoff, min_mapq, gap_, gap_mapq).astype(np.int64)
+    return Candidates(**{k: rows[:, j] for j, k in enumerate(Candidates.FIELDS)})

@@ -107,6 +107,32 @@ int coral_point_cover(const coral_records_t *rec, int32_t n_pts, const int32_t *
                       uint32_t pair_cap, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * coral_bp_candidates — breakpoint candidates from the chimeric (SA-derived) local alignments of many reads.
+ *
+ * Replaces the per-read loops over alignment2bp_l (/root/reference/src/infer_breakpoint_graph.py:687-688 ->
+ * breakpoint_utilities.py:129-186; mode 0, all amplicon intervals) and alignment2bp (infer_breakpoint_graph.py:432-434
+ * -> breakpoint_utilities.py:70-96; mode 1, exactly two intervals I1, I2), including interval2bp
+ * (breakpoint_utilities.py:289-295).  The chimeric table is a device SoA: rows of read r are off[r]..off[r+1], in the
+ * reference's (qs, qe)-sorted order; ra/rb are rint[1]/rint[2] (ra > rb on '-' rows); strand 0 '+', 1 '-'.
+ * `sel` lists the reads to process in iteration order (NULL = all reads).  Output rows are 13 int32:
+ * c1, p1, o1, c2, p2, o2, read, i, j, query gap, swapped flag, mapq of the first, mapq of the second segment — in the
+ * reference's order (reads as listed; per read consecutive-pair candidates, then skip-one candidates).
+ * `counts` is a device workspace of n_sel + 2 int32.  *n_out (host) receives the number of candidates; when it
+ * exceeds `cap` the call returns CORAL_ERR_CAPACITY and must be repeated with a larger buffer.  Synchronises `stream`.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct coral_chimeric {
+    int32_t n_reads;
+    const int32_t *off;                                     /* [n_reads + 1] */
+    const int32_t *qs, *qe, *tid, *ra, *rb, *strand, *mapq; /* per row */
+} coral_chimeric_t;
+
+int coral_bp_candidates(const coral_chimeric_t *ct, int32_t n_sel, const int32_t *sel, int32_t mode, int32_t n_int,
+                        const int32_t *int_tid, const int32_t *int_start, const int32_t *int_end,
+                        const int32_t *chr_rank, int32_t n_tid, int32_t min_bp_match_cutoff, int32_t min_mapq,
+                        int32_t gap_, int32_t gap_mapq, int32_t *counts, int32_t *cand /* [cap][13] */, int32_t cap,
+                        int32_t *n_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * coral_read_counter — copy a device counter to the host (synchronises `stream`).
  * ------------------------------------------------------------------------------------------------ */
 int coral_read_counter(const uint32_t *dev_counter, uint32_t *host_value, void *stream);

@@ -129,3 +129,66 @@ def test_empty_inputs():
     nr, nb = kernels.segment_coverage(dr, res, [(0, 0, 100)])
     assert nr.tolist() == [0] and nb.tolist() == [0]
     assert [g.tolist() for g in kernels.point_cover(dr, [(0, 5)])] == [[]]
+
+
+def _table_from_cas(cas, chroms):
+    """ChimericTable holding the given (qint, rint, qual) tuples, one read each (rint '-' rows keep ra > rb)."""
+    from coral_amd.chimeric import ChimericTable
+    T = ChimericTable()
+    tid_of = {c: k for k, c in enumerate(chroms)}
+    off, cols = [0], {k: [] for k in ("qs", "qe", "tid", "ra", "rb", "strand", "mapq", "read")}
+    for r, (qint, rint, qual) in enumerate(cas):
+        for q, ri, mq in zip(qint, rint, qual):
+            cols["qs"].append(q[0]); cols["qe"].append(q[1]); cols["tid"].append(tid_of[ri[0]])
+            cols["ra"].append(ri[1]); cols["rb"].append(ri[2]); cols["strand"].append(0 if ri[3] == "+" else 1)
+            cols["mapq"].append(mq); cols["read"].append(r)
+        off.append(len(cols["qs"]))
+    T.off = np.array(off, dtype=np.int64)
+    for k, v in cols.items():
+        setattr(T, k, np.array(v, dtype=np.int64))
+    T.name_id = np.arange(len(cas), dtype=np.int64)
+    T.failed = np.zeros(len(cas), dtype=bool)
+    return T
+
+
+def test_bp_candidates_against_reference_vectors(golden_dir):
+    """coral_bp_candidates vs the known-answer vectors of the REFERENCE's alignment2bp / alignment2bp_l
+    (tests/golden/unit_vectors.json), one launch per vector and one batched launch for mode 0."""
+    import json, os
+    from coral_amd import kernels, synth
+    from coral_amd.records import DeviceRecords
+    from coral_amd.global_names import chr_idx
+    from tests.canon import uncanon_unit
+    with open(os.path.join(golden_dir, "unit_vectors.json")) as fp:
+        vec = json.load(fp)
+    chroms = synth.CHROMS
+    dr = DeviceRecords(synth.records_from_alignments([]), "cuda:0")
+    chr_rank = np.array([chr_idx[c] for c in chroms], dtype=np.int64)
+    tid_of = {c: k for k, c in enumerate(chroms)}
+
+    def as_lists(cands, name_of):
+        out = []
+        for k in range(len(cands)):
+            out.append([chroms[cands.c1[k]], int(cands.p1[k]), "+-"[cands.o1[k]], chroms[cands.c2[k]], int(cands.p2[k]), "+-"[cands.o2[k]],
+                        (name_of(int(cands.read[k])), int(cands.i[k]), int(cands.j[k])), int(cands.gap[k]), int(cands.swapped[k]),
+                        int(cands.mqa[k]), int(cands.mqb[k])])
+        return out
+    n_pos = 0
+    for k, v in enumerate(vec["alignment2bp"]):
+        ca = uncanon_unit(v["ca"])
+        T = _table_from_cas([ca], chroms)
+        iv = [(tid_of[v["i1"][0]], v["i1"][1], v["i1"][2]), (tid_of[v["i2"][0]], v["i2"][1], v["i2"][2])]
+        got = as_lists(kernels.bp_candidates(dr, T, np.array([0]), 1, iv, chr_rank, 100, 20, 100, 10), lambda r: "rd%d" % k)
+        assert got == uncanon_unit(v["out"]), k
+        n_pos += len(got)
+    assert n_pos > 30
+    cas = [uncanon_unit(v["ca"]) for v in vec["alignment2bp_l"]]
+    ivs = [(tid_of[i[0]], i[1], i[2]) for i in vec["alignment2bp_l"][0]["intervals"]]
+    T = _table_from_cas(cas, chroms)
+    got = as_lists(kernels.bp_candidates(dr, T, None, 0, ivs, chr_rank, 100, 20, 100, 10), lambda r: "rd%d" % r)
+    exp = [c for v in vec["alignment2bp_l"] for c in uncanon_unit(v["out"])]
+    assert got == exp and len(exp) > 30
+    # a subset in a permuted order keeps that order
+    sel = np.array([7, 3, 200, 11, 0], dtype=np.int64)
+    got = as_lists(kernels.bp_candidates(dr, T, sel, 0, ivs, chr_rank, 100, 20, 100, 10), lambda r: "rd%d" % r)
+    assert got == [c for s in sel for c in uncanon_unit(vec["alignment2bp_l"][int(s)]["out"])]
