@@ -7,72 +7,75 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
 #include "../../include/coral_hip.h"
 
 namespace {
-struct Cluster {
-    std::vector<int64_t> a, b;                  // distinct (p1, p2) members
-    std::unordered_set<uint64_t> seen;
-    int64_t amin, amax, bmin, bmax;
+struct Member {
+    int64_t a, b;
+    int32_t cluster;      // lowest-numbered cluster that contains a candidate with exactly these coordinates
 };
-inline uint64_t mix(int64_t a, int64_t b) {
-    uint64_t x = (uint64_t)a * 0x9E3779B97F4A7C15ull ^ ((uint64_t)b + 0x7F4A7C15ull + ((uint64_t)a << 6));
-    return x;
+inline uint64_t cell_key(int64_t cx, int64_t cy) {
+    return (uint64_t)cx * 0x9E3779B97F4A7C15ull ^ ((uint64_t)cy + 0x7F4A7C15F39CC060ull + ((uint64_t)cx << 6) + ((uint64_t)cx >> 2));
 }
+struct Cell {
+    int64_t cx, cy;
+    std::vector<Member> m;
+};
 }  // namespace
 
+// "Join the FIRST existing cluster that has any member within `cutoff` at both ends" == the lowest cluster ordinal
+// among all earlier candidates within range (clusters are numbered in creation order).  A uniform grid of cell size
+// `cutoff` over (p1, p2) bounds the search to the 3 x 3 neighbouring cells, and only distinct coordinates are kept per
+// cell (with the lowest cluster they belong to), so N near-identical candidates cost O(N * distinct) and N scattered
+// singletons cost O(N), instead of the O(N^2) scan of the reference.  Exact: every comparison is on the coordinates.
 extern "C" int coral_cluster_first_fit(int64_t n, const int64_t *p1, const int64_t *p2, int64_t cutoff,
                                        int32_t *cluster_of, int32_t *n_clusters) {
-    if (n < 0 || (n > 0 && (!p1 || !p2 || !cluster_of)) || !n_clusters) return CORAL_ERR_ARG;
-    std::vector<Cluster> cl;
+    if (n < 0 || cutoff <= 0 || (n > 0 && (!p1 || !p2 || !cluster_of)) || !n_clusters) return CORAL_ERR_ARG;
+    std::unordered_map<uint64_t, std::vector<Cell>> grid;       // hash -> cells (collisions resolved by exact cx, cy)
+    grid.reserve((size_t)n * 2 + 16);
+    auto floor_div = [](int64_t v, int64_t d) { return v >= 0 ? v / d : -((-v + d - 1) / d); };
+    int32_t ncl = 0;
     for (int64_t i = 0; i < n; ++i) {
         const int64_t x = p1[i], y = p2[i];
-        int home = -1;
-        for (size_t c = 0; c < cl.size() && home < 0; ++c) {
-            Cluster &k = cl[c];
-            if (x - k.amax >= cutoff || k.amin - x >= cutoff || y - k.bmax >= cutoff || k.bmin - y >= cutoff) continue;
-            const size_t m = k.a.size();
-            for (size_t j = 0; j < m; ++j) {
-                if (llabs(x - k.a[j]) < cutoff && llabs(y - k.b[j]) < cutoff) {
-                    home = (int)c;
-                    break;
+        const int64_t cx = floor_div(x, cutoff), cy = floor_div(y, cutoff);
+        int32_t best = INT32_MAX;
+        for (int64_t dx = -1; dx <= 1; ++dx)
+            for (int64_t dy = -1; dy <= 1; ++dy) {
+                auto it = grid.find(cell_key(cx + dx, cy + dy));
+                if (it == grid.end()) continue;
+                for (const Cell &c : it->second) {
+                    if (c.cx != cx + dx || c.cy != cy + dy) continue;
+                    for (const Member &m : c.m)
+                        if (m.cluster < best && llabs(x - m.a) < cutoff && llabs(y - m.b) < cutoff) best = m.cluster;
                 }
             }
+        if (best == INT32_MAX) best = ncl++;
+        cluster_of[i] = best;
+        std::vector<Cell> &bucket = grid[cell_key(cx, cy)];
+        Cell *cell = nullptr;
+        for (Cell &c : bucket)
+            if (c.cx == cx && c.cy == cy) {
+                cell = &c;
+                break;
+            }
+        if (!cell) {
+            bucket.push_back(Cell{cx, cy, {}});
+            cell = &bucket.back();
         }
-        if (home < 0) {
-            cl.emplace_back();
-            home = (int)cl.size() - 1;
-            Cluster &k = cl[home];
-            k.amin = k.amax = x;
-            k.bmin = k.bmax = y;
-        }
-        Cluster &k = cl[home];
-        // identical coordinates add no information to later membership tests: keep each pair once.
-        // (exact 128-bit identity is checked on hash hits, so a hash collision can never drop a pair)
-        const uint64_t h = mix(x, y);
-        bool dup = false;
-        if (k.seen.count(h)) {
-            for (size_t j = 0; j < k.a.size(); ++j)
-                if (k.a[j] == x && k.b[j] == y) {
-                    dup = true;
-                    break;
-                }
-        }
-        if (!dup) {
-            k.seen.insert(h);
-            k.a.push_back(x);
-            k.b.push_back(y);
-            if (x < k.amin) k.amin = x;
-            if (x > k.amax) k.amax = x;
-            if (y < k.bmin) k.bmin = y;
-            if (y > k.bmax) k.bmax = y;
-        }
-        cluster_of[i] = home;
+        bool found = false;
+        for (Member &m : cell->m)
+            if (m.a == x && m.b == y) {
+                if (best < m.cluster) m.cluster = best;
+                found = true;
+                break;
+            }
+        if (!found) cell->m.push_back(Member{x, y, best});
     }
-    *n_clusters = (int32_t)cl.size();
+    *n_clusters = ncl;
     return CORAL_OK;
 }
 

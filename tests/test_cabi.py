@@ -51,3 +51,40 @@ def test_product_fails_loudly_without_library(monkeypatch, tmp_path):
     import pytest
     with pytest.raises(_lib.CoralHipError):
         _lib.lib()
+
+
+def test_first_fit_equals_quadratic_definition():
+    """The grid-indexed coral_cluster_first_fit is EXACTLY the greedy loop of bu:268-282 (checked against a direct O(n^2)
+    transcription of its definition on random inputs with chaining, several cutoffs and negative coordinates)."""
+    import numpy as np
+    from coral_amd import _lib
+    L = _lib.lib()
+
+    def definition(p1, p2, cut):
+        clusters, out = [], []
+        for x, y in zip(p1, p2):
+            home = -1
+            for ci, c in enumerate(clusters):
+                if any(abs(x - a) < cut and abs(y - b) < cut for a, b in c):
+                    home = ci
+                    break
+            if home < 0:
+                clusters.append([])
+                home = len(clusters) - 1
+            clusters[home].append((x, y))
+            out.append(home)
+        return out
+    rng = np.random.default_rng(3)
+    for trial in range(150):
+        n = int(rng.integers(1, 100))
+        cut = int(rng.choice([5, 50, 2000]))
+        centres = rng.integers(-3 * cut, 20 * cut, size=(int(rng.integers(1, 6)), 2))
+        c = centres[rng.integers(0, len(centres), n)]
+        sp = int(rng.choice([1, cut // 2 + 1, cut, 3 * cut]))
+        p1 = (c[:, 0] + rng.integers(-sp, sp + 1, n)).astype(np.int64)
+        p2 = (c[:, 1] + rng.integers(-sp, sp + 1, n)).astype(np.int64)
+        out = np.empty(n, dtype=np.int32)
+        k = ctypes.c_int32(0)
+        _lib.check(L.coral_cluster_first_fit(n, p1.ctypes.data, p2.ctypes.data, cut, out.ctypes.data, ctypes.byref(k)), "ff")
+        exp = definition(p1.tolist(), p2.tolist(), cut)
+        assert out.tolist() == exp and k.value == max(exp) + 1
