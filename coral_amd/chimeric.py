@@ -103,8 +103,8 @@ def build_chimeric_table(dr) -> ChimericTable:
     rl = np.full(dr.n_names, -1, dtype=np.int64)
     idx = np.nonzero(mapped & (dr.h_flag < 256))[0]
     if len(idx):
-        u, first = np.unique(nid[idx], return_index=True)
-        rl[u] = dr.h_qlen[idx[first]]
+        rev = idx[::-1]
+        rl[nid[rev]] = dr.h_qlen[rev]          # duplicate indices: the last write wins -> the FIRST record in file order
     T.read_length = rl
     sa_cnt = np.diff(dr.h_sa_off)
     has_sa = (sa_cnt > 0) & mapped
@@ -129,9 +129,11 @@ def build_chimeric_table(dr) -> ChimericTable:
     fields = fields[is_first.astype(bool)]
     row_name = fields[:, 0]
     # dict insertion order: first SA-bearing record of each name
-    u, f = np.unique(row_name, return_index=True)
+    first_row = np.full(dr.n_names, -1, dtype=np.int64)
+    first_row[row_name[::-1]] = np.arange(len(row_name) - 1, -1, -1)          # first row of every name (last write wins)
+    has_rows = np.nonzero(first_row >= 0)[0]
+    order_names = has_rows[np.argsort(first_row[has_rows], kind="stable")]
     rank_of_name = np.empty(dr.n_names, dtype=np.int64)
-    order_names = u[np.argsort(f, kind="stable")]
     rank_of_name[order_names] = np.arange(len(order_names))
     # drop reads without a primary alignment (ibg:163-173)
     has_primary = rl[order_names] >= 0
@@ -146,7 +148,7 @@ def build_chimeric_table(dr) -> ChimericTable:
     shape = np.where(m <= 0, SHAPE_NO_S_OR_M, shape)
     shape = np.where(c5 == -2, SHAPE_UNKNOWN, shape)          # decoder marks unparseable CIGAR shapes with c5 = -2
     # a read fails as a whole at its first offending entry (cp:246-255)
-    order0 = np.lexsort((np.arange(len(read)), read))
+    order0 = np.argsort(read, kind="stable")
     read, tid, pos1, strand, c5, m, x, c3, mapq, nm, shape = (a[order0] for a in (read, tid, pos1, strand, c5, m, x, c3, mapq, nm, shape))
     bad = shape != SHAPE_OK
     failed = np.zeros(R, dtype=bool)
