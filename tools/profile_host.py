@@ -17,4 +17,6 @@ b = sharding.build_graph_sharded(dr, seeds, cn, os.path.join(work, "p"))
 pr.disable(); print("step %.2fs  graphs %d  bps %d  chimeric %d" % (time.time() - t, len(b.lr_graph), len(b.new_bp_list), len(b.chimeric_alignments)), flush=True)
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45); print(s.getvalue())
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(25); print(s.getvalue())
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_callees("find_smalldel_breakpoints|assign_cov|build_chimeric_table|find_interval_i"); print(s.getvalue()[:9000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_callees("find_smalldel_breakpoints"); print(s.getvalue()[:6000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_callees("_add_clustered|_call_breakpoints"); print(s.getvalue()[:6000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_callees("assign_cov"); print(s.getvalue()[:5000])
