@@ -56,6 +56,10 @@ def lib():
     L.coral_bp_candidates.argtypes = [C.POINTER(coral_chimeric_t), C.c_int32, P, C.c_int32, C.c_int32, P, P, P, P, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, C.c_int32, C.POINTER(C.c_int32), P]
     L.coral_bp_candidates.restype = C.c_int
+    L.coral_sa_table.argtypes = [C.c_int32, P, P, P, P, C.c_int32, C.c_int32, P, P, P, P, C.c_int64, P, P, P, P, P,
+                                 C.POINTER(C.c_int32), P]
+    L.coral_sa_table.restype = C.c_int
+    L.coral_sa_last_error.restype = C.c_char_p
     L.coral_cluster_first_fit.argtypes = [C.c_int64, P, P, C.c_int64, P, C.POINTER(C.c_int32)]
     L.coral_cluster_first_fit.restype = C.c_int
     L.coral_bam_decode_open.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]

@@ -53,130 +53,25 @@ class ChimericTable:
         return len(self.qs)
 
 
-def _parse_rows(c5, m, x, c3, strand, rl):
-    """Vectorised cigar2pos* (cp:17-215).  Returns qs, qe, al."""
-    fwd = strand == 0
-    has5, has3 = c5 > 0, c3 > 0
-    ins, dele = x > 0, x < 0
-    al = m + np.where(dele, -x, 0)
-    both = has5 & has3
-    only5 = has5 & ~has3
-    only3 = ~has5 & has3
-    plain = ~ins & ~dele
-    qs = np.zeros_like(m)
-    qe = np.zeros_like(m)
-    # clip on the 5' side only: SM / SMD / SMI
-    s = only5 & fwd
-    qs[s] = c5[s]; qe[s] = rl[s] - 1
-    s = only5 & ~fwd & plain
-    qs[s] = 0; qe[s] = al[s] - 1
-    s = only5 & ~fwd & dele
-    qs[s] = 0; qe[s] = m[s] - 1
-    s = only5 & ~fwd & ins
-    qs[s] = 0; qe[s] = rl[s] - c5[s] - 1
-    # clip on the 3' side only: MS / MDS / MIS
-    s = only3 & ~fwd
-    qs[s] = c3[s]; qe[s] = rl[s] - 1
-    s = only3 & fwd & plain
-    qs[s] = 0; qe[s] = al[s] - 1
-    s = only3 & fwd & dele
-    qs[s] = 0; qe[s] = m[s] - 1
-    s = only3 & fwd & ins
-    qs[s] = 0; qe[s] = rl[s] - c3[s] - 1
-    # both clips: SMS / SMDS / SMIS
-    s = both & plain
-    qs[s] = np.where(fwd[s], c5[s], c3[s]); qe[s] = qs[s] + al[s] - 1
-    s = both & ~plain & fwd
-    qs[s] = c5[s]; qe[s] = rl[s] - c3[s] - 1
-    s = both & ~plain & ~fwd
-    qs[s] = c3[s]; qe[s] = rl[s] - c5[s] - 1
-    return qs, qe, al
-
-
 def build_chimeric_table(dr) -> ChimericTable:
-    """ibg:139-174 + cp:232-269 on the decoded records ``dr`` (a DeviceRecords; host mirrors are used)."""
+    """ibg:139-174 + cp:232-269 for all reads: coral_sa_table (K3) does the SA-row work on the GPU; this wrapper adds the
+    float NM rate (cp:268) and the NM statistics of the non-chimeric MAPQ-60 records (ibg:153-157)."""
+    from . import kernels
     T = ChimericTable()
-    n = dr.n_total
     mapped = dr.h_tid >= 0
-    nid = dr.h_name_id.astype(np.int64)
-    # read_length[name] = query_length of the first record with flag < 256 (ibg:142-143)
-    rl = np.full(dr.n_names, -1, dtype=np.int64)
-    idx = np.nonzero(mapped & (dr.h_flag < 256))[0]
-    if len(idx):
-        rev = idx[::-1]
-        rl[nid[rev]] = dr.h_qlen[rev]          # duplicate indices: the last write wins -> the FIRST record in file order
-    T.read_length = rl
-    sa_cnt = np.diff(dr.h_sa_off)
-    has_sa = (sa_cnt > 0) & mapped
-    # records without SA and MAPQ 60 feed nm_stats (ibg:153-157); the count must be non-zero (ibg:159)
+    has_sa = (np.diff(dr.h_sa_off) > 0) & mapped
     plain60 = mapped & ~has_sa & (dr.h_mapq == 60)
     T.n_mapq60_plain = int(plain60.sum())
     T.nm_e = dr.h_nm[plain60] / dr.h_qlen[plain60].astype(np.float64) if T.n_mapq60_plain else np.zeros(0)
-    if not has_sa.any():
-        return T
-    # SA rows are stored record by record, so rows of records with SA are simply all rows of mapped records
-    all_rec_of_row = np.repeat(np.arange(n), sa_cnt)
-    keep_mapped = mapped[all_rec_of_row]
-    row_idx = np.nonzero(keep_mapped)[0]
-    row_name = nid[all_rec_of_row[row_idx]]
-    fields = np.column_stack([row_name, dr.h_sa[row_idx].astype(np.int64), dr.h_sa_nm[row_idx].astype(np.int64)])
-    # first-seen de-duplication by string equality == equality of all tokens (ibg:146-151)
-    from . import _lib
-    fields = np.ascontiguousarray(fields)
-    is_first = np.empty(len(fields), dtype=np.uint8)
-    _lib.check(_lib.lib().coral_first_seen_rows(len(fields), fields.shape[1], fields.ctypes.data, is_first.ctypes.data),
-               "coral_first_seen_rows")
-    fields = fields[is_first.astype(bool)]
-    row_name = fields[:, 0]
-    # dict insertion order: first SA-bearing record of each name
-    first_row = np.full(dr.n_names, -1, dtype=np.int64)
-    first_row[row_name[::-1]] = np.arange(len(row_name) - 1, -1, -1)          # first row of every name (last write wins)
-    has_rows = np.nonzero(first_row >= 0)[0]
-    order_names = has_rows[np.argsort(first_row[has_rows], kind="stable")]
-    rank_of_name = np.empty(dr.n_names, dtype=np.int64)
-    rank_of_name[order_names] = np.arange(len(order_names))
-    # drop reads without a primary alignment (ibg:163-173)
-    has_primary = rl[order_names] >= 0
-    new_rank = np.cumsum(has_primary) - 1
-    keep = has_primary[rank_of_name[row_name]]
-    fields = fields[keep]
-    read = new_rank[rank_of_name[fields[:, 0]]]
-    read_names = order_names[has_primary]
-    R = len(read_names)
-    tid, pos1, strand, c5, m, x, c3, mapq, nm = (fields[:, k] for k in range(1, 10))
-    shape = np.where((c5 <= 0) & (c3 <= 0), SHAPE_NO_S_OR_M, SHAPE_OK)
-    shape = np.where(m <= 0, SHAPE_NO_S_OR_M, shape)
-    shape = np.where(c5 == -2, SHAPE_UNKNOWN, shape)          # decoder marks unparseable CIGAR shapes with c5 = -2
-    # a read fails as a whole at its first offending entry (cp:246-255)
-    order0 = np.argsort(read, kind="stable")
-    read, tid, pos1, strand, c5, m, x, c3, mapq, nm, shape = (a[order0] for a in (read, tid, pos1, strand, c5, m, x, c3, mapq, nm, shape))
-    bad = shape != SHAPE_OK
-    failed = np.zeros(R, dtype=bool)
-    if bad.any():
-        first_bad = np.full(R, -1, dtype=np.int64)
-        bi = np.nonzero(bad)[0][::-1]
-        first_bad[read[bi]] = bi
-        fb = first_bad[first_bad >= 0]
-        if (shape[fb] == SHAPE_UNKNOWN).any():
-            raise KeyError("SA CIGAR shape outside SM/MS/SMS/SMD/MDS/SMDS/SMI/MIS/SMIS")     # cp:255
-        failed[read[fb]] = True
-    ok = ~failed[read]
-    read, tid, pos1, strand, c5, m, x, c3, mapq, nm = (a[ok] for a in (read, tid, pos1, strand, c5, m, x, c3, mapq, nm))
-    qs, qe, al = _parse_rows(c5, m, x, c3, strand, rl[read_names[read]])
-    ra = np.where(strand == 0, pos1 - 1, pos1 + al - 2)
-    rb = np.where(strand == 0, pos1 + al - 2, pos1 - 1)
-    order = np.lexsort((np.arange(len(read)), qe, qs, read))       # stable (qs, qe) sort inside each read (cp:263)
-    read, tid, strand, mapq, nm, qs, qe, ra, rb = (a[order] for a in (read, tid, strand, mapq, nm, qs, qe, ra, rb))
-    if ((qe - qs) == 0).any():
-        raise ZeroDivisionError("float division by zero")                            # cp:268
-    T.name_id = read_names
-    T.failed = failed
-    T.off = np.zeros(R + 1, dtype=np.int64)
-    np.cumsum(np.bincount(read, minlength=R), out=T.off[1:])
-    T.read, T.qs, T.qe, T.tid, T.ra, T.rb, T.strand, T.mapq = read, qs, qe, tid, ra, rb, strand, mapq
-    T.nm = nm.astype(np.float64) / (qe - qs)
-    T.cni0 = np.full(len(read), -1, dtype=np.int64)
-    T.cni1 = np.full(len(read), -1, dtype=np.int64)
+    rows, off, name_id, failed, rl = kernels.sa_table(dr)
+    T.read_length = rl
+    T.name_id, T.failed, T.off = name_id, failed, off
+    r64 = rows.astype(np.int64)
+    T.qs, T.qe, T.tid, T.ra, T.rb, T.strand, T.mapq = (r64[:, k] for k in range(7))
+    T.read = np.repeat(np.arange(len(name_id), dtype=np.int64), np.diff(off))
+    T.nm = r64[:, 7].astype(np.float64) / (T.qe - T.qs) if len(r64) else np.zeros(0)
+    T.cni0 = np.full(len(r64), -1, dtype=np.int64)
+    T.cni1 = np.full(len(r64), -1, dtype=np.int64)
     return T
 
 

@@ -225,3 +225,44 @@ def bp_candidates(dr, T, sel, mode: int, intervals, chr_rank, cutoff=100, min_ma
     from .chimeric import Candidates
     rows = _bp_candidates_local(dr, T, sel, mode, intervals, chr_rank, cutoff, min_mapq, gap_, gap_mapq).astype(np.int64)
     return Candidates(**{k: rows[:, j] for j, k in enumerate(Candidates.FIELDS)})
+
+
+def _sa_table_local(dr):
+    """coral_sa_table on this process's GPU over ALL records' SA rows (they are tiny next to the CIGARs; the table is
+    consumed by the host logic, so it is built where that runs).  Returns numpy arrays
+    (rows int32[n_rows, 8], off int64[n_reads + 1], name_id, failed, read_length)."""
+    L = _lib.lib()
+    dev = dr.device
+    d = dr.sa_device_arrays()
+    n_sa = dr.n_sa
+    ws_bytes = max(1 << 20, 96 * max(n_sa, 1) + 8 * dr.n_names + (8 << 20))
+    out_rows = torch.empty((max(n_sa, 1), 8), dtype=torch.int32, device=dev)
+    out_off = torch.empty(max(n_sa, 1) + 1, dtype=torch.int32, device=dev)
+    out_name = torch.empty(max(n_sa, 1), dtype=torch.int32, device=dev)
+    out_failed = torch.empty(max(n_sa, 1), dtype=torch.int32, device=dev)
+    out_rl = torch.empty(max(dr.n_names, 1), dtype=torch.int32, device=dev)
+    counts = (C.c_int32 * 2)()
+    while True:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        rc = L.coral_sa_table(dr.n_total, d["tid"].data_ptr(), d["flagmq"].data_ptr(), d["qlen"].data_ptr(), d["name"].data_ptr(),
+                              dr.n_names, n_sa, d["sa"].data_ptr(), d["sa_nm"].data_ptr(), d["sa_rec"].data_ptr(), ws.data_ptr(),
+                              ws_bytes, out_rows.data_ptr(), out_off.data_ptr(), out_name.data_ptr(), out_failed.data_ptr(),
+                              out_rl.data_ptr(), counts, dr.stream())
+        if rc == -3:
+            ws_bytes = (int(counts[0]) + 1) << 20
+            continue
+        break
+    if rc == -4:
+        raise KeyError("SA CIGAR shape outside SM/MS/SMS/SMD/MDS/SMDS/SMI/MIS/SMIS")        # cp:255
+    if rc == -5:
+        raise ZeroDivisionError("float division by zero")                                # cp:268
+    if rc != 0:
+        raise _lib.CoralHipError("coral_sa_table failed (%d): %s" % (rc, L.coral_sa_last_error().decode()))
+    n_reads, n_rows = int(counts[0]), int(counts[1])
+    return (out_rows[:n_rows].cpu().numpy(), out_off[:n_reads + 1].cpu().numpy().astype(np.int64),
+            out_name[:n_reads].cpu().numpy().astype(np.int64), out_failed[:n_reads].cpu().numpy().astype(bool),
+            out_rl[:dr.n_names].cpu().numpy().astype(np.int64))
+
+
+def sa_table(dr):
+    return _sa_table_local(dr)

@@ -106,6 +106,19 @@ class DeviceRecords:
                                     self.flagmq.data_ptr(), self.n_cigar.data_ptr(), self.cigar_off.data_ptr(),
                                     self.cigar.data_ptr())
 
+    def sa_device_arrays(self):
+        """Device copies of what coral_sa_table reads (whole file; uploaded once, ~40 B per SA row + 16 B per record)."""
+        if getattr(self, "_sa_dev", None) is None:
+            up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+            flagmq = (self.h_flag.astype(np.int64) & 0xFFFF) | ((self.h_mapq.astype(np.int64) & 0xFF) << 16)
+            sa_rec = np.repeat(np.arange(self.n_total, dtype=np.int32), np.diff(self.h_sa_off))
+            sa = self.h_sa if len(self.h_sa) else np.zeros((1, 8), dtype=np.int32)
+            self._sa_dev = dict(tid=up(self.h_tid), flagmq=up(flagmq.astype(np.int32)), qlen=up(self.h_qlen),
+                                name=up(self.h_name_id), sa=up(sa.astype(np.int32)),
+                                sa_nm=up(self.h_sa_nm if len(self.h_sa_nm) else np.zeros(1, dtype=np.int32)),
+                                sa_rec=up(sa_rec if len(sa_rec) else np.zeros(1, dtype=np.int32)))
+        return self._sa_dev
+
     def stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 

@@ -107,6 +107,29 @@ int coral_point_cover(const coral_records_t *rec, int32_t n_pts, const int32_t *
                       uint32_t pair_cap, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * coral_sa_table — the chimeric-alignment table of ALL reads from the tokenised SA rows (device in, device out).
+ *
+ * Replaces the SA-tag half of fetch() (/root/reference/src/infer_breakpoint_graph.py:139-174: first-seen
+ * de-duplication of SA entries per read name, read_length = query_length of the first record with flag < 256,
+ * reads without a primary dropped) and alignment_from_satags with the nine cigar2pos* shapes
+ * (/root/reference/src/cigar_parsing.py:17-269), including the stable (qs, qe) sort.
+ *   inputs  rec_tid / rec_flagmq / rec_qlen (pysam query_length) / rec_name : int32[n_rec];
+ *           sa int32[n_sa][8] (layout of coral_bam_decode_*), sa_nm int32[n_sa], sa_rec int32[n_sa] owner record
+ *   outputs out_rows int32[<= n_sa][8] = qs, qe, tid, rint[1], rint[2], strand, mapq, NM (rows of read i are
+ *           out_off[i]..out_off[i+1], sorted by (qs, qe)); out_name / out_failed int32[<= n_sa] per read (failed = the
+ *           read's value is the reference's ([], [], [])); reads are in the insertion order of the reference's dict;
+ *           out_read_length int32[n_names] (-1 = no primary seen);  counts (HOST) = {n_reads, n_rows}
+ * `workspace` is device scratch; when it is too small the call returns CORAL_ERR_CAPACITY with counts[0] = MiB needed.
+ * Errors mirror the reference: CORAL_ERR_FORMAT = SA CIGAR outside the nine shapes (KeyError, cp:255),
+ * CORAL_ERR_FORMAT - 1 = zero-length query interval (ZeroDivisionError, cp:268).  Synchronises `stream`.
+ * ------------------------------------------------------------------------------------------------ */
+int coral_sa_table(int32_t n_rec, const int32_t *rec_tid, const int32_t *rec_flagmq, const int32_t *rec_qlen,
+                   const int32_t *rec_name, int32_t n_names, int32_t n_sa, const int32_t *sa, const int32_t *sa_nm,
+                   const int32_t *sa_rec, void *workspace, int64_t workspace_bytes, int32_t *out_rows, int32_t *out_off,
+                   int32_t *out_name, int32_t *out_failed, int32_t *out_read_length, int32_t *counts, void *stream);
+const char *coral_sa_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
  * coral_bp_candidates — breakpoint candidates from the chimeric (SA-derived) local alignments of many reads.
  *
  * Replaces the per-read loops over alignment2bp_l (/root/reference/src/infer_breakpoint_graph.py:687-688 ->

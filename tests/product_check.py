@@ -198,6 +198,30 @@ def install_cpu_kernel_fakes(monkeypatch):
                 rows.append([tid_of[c[0]], c[1], ori[c[2]], tid_of[c[3]], c[4], ori[c[5]], c[6][0], c[6][1], c[6][2], c[7], c[8], c[9], c[10]])
         return np.array(rows, dtype=np.int32).reshape(-1, 13)
 
+    def sa_table_local(dr):
+        """coral_sa_table stand-in: the oracle's fetch() (string SA entries, per-read Python lists) turned into arrays."""
+        from oracle import coral_oracle as O
+        h = host_of(dr)
+        ob = O.OracleGraphBuild.__new__(O.OracleGraphBuild)
+        ob.rec, ob.read_length, ob.chimeric_alignments, ob.nm_stats = h, {}, {}, [0.0, 0.0, 0]
+        ob.fetch()
+        name_id_of = {nm: k for k, nm in enumerate(h.names)}
+        tid_of = {c: k for k, c in enumerate(h.chroms)}
+        rows, off, names, failed = [], [0], [], []
+        for rn, ca in ob.chimeric_alignments.items():
+            names.append(name_id_of[rn])
+            failed.append(len(ca) == 3)
+            if len(ca) == 4:
+                for q, ri, mq, nmr in zip(*ca):
+                    rows.append([q[0], q[1], tid_of[ri[0]], ri[1], ri[2], 0 if ri[3] == "+" else 1, mq, int(round(nmr * (q[1] - q[0])))])
+            off.append(len(rows))
+        rl = np.full(len(h.names), -1, dtype=np.int64)
+        for rn, v in ob.read_length.items():
+            rl[name_id_of[rn]] = v
+        return (np.array(rows, dtype=np.int32).reshape(-1, 8), np.array(off, dtype=np.int64), np.array(names, dtype=np.int64),
+                np.array(failed, dtype=bool), rl)
+
+    monkeypatch.setattr(kernels, "_sa_table_local", sa_table_local)
     monkeypatch.setattr(kernels, "_bp_candidates_local", bp_candidates_local)
     monkeypatch.setattr(kernels, "_scan_local", scan_local)
     monkeypatch.setattr(kernels, "_coverage_local", coverage_local)

@@ -192,3 +192,53 @@ def test_bp_candidates_against_reference_vectors(golden_dir):
     sel = np.array([7, 3, 200, 11, 0], dtype=np.int64)
     got = as_lists(kernels.bp_candidates(dr, T, sel, 0, ivs, chr_rank, 100, 20, 100, 10), lambda r: "rd%d" % r)
     assert got == [c for s in sel for c in uncanon_unit(vec["alignment2bp_l"][int(s)]["out"])]
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_edge", "small", "ultra"])
+def test_sa_table_matches_oracle_fetch(name):
+    """coral_sa_table (K3) vs the oracle's fetch(): same reads in the same (dict) order, same failed reads, same rows
+    (qs, qe, rint, mapq, NM rate) in the same (qs, qe)-sorted order, same read lengths."""
+    from coral_amd import kernels
+    from coral_amd.chimeric import build_chimeric_table
+    from coral_amd.records import DeviceRecords
+    from oracle import coral_oracle as O
+    from oracle.hostrecords import HostRecords
+    cfg, rec = synth.dataset(name, "cpu")
+    h = HostRecords(rec)
+    ob = O.OracleGraphBuild.__new__(O.OracleGraphBuild)
+    ob.rec, ob.read_length, ob.chimeric_alignments, ob.nm_stats = h, {}, {}, [0.0, 0.0, 0]
+    ob.fetch()
+    dr = DeviceRecords(rec, "cuda:0")
+    T = build_chimeric_table(dr)
+    names = dr.names
+    assert [names[i] for i in T.name_id] == list(ob.chimeric_alignments)
+    assert {names[i]: int(v) for i, v in enumerate(T.read_length) if v >= 0} == ob.read_length
+    for r, (rn, ca) in enumerate(ob.chimeric_alignments.items()):
+        a, b = int(T.off[r]), int(T.off[r + 1])
+        if len(ca) == 3:
+            assert T.failed[r] and a == b
+            continue
+        assert not T.failed[r]
+        assert [[int(T.qs[k]), int(T.qe[k])] for k in range(a, b)] == ca[0]
+        assert [[dr.header_chroms[T.tid[k]], int(T.ra[k]), int(T.rb[k]), "+-"[T.strand[k]]] for k in range(a, b)] == ca[1]
+        assert [int(T.mapq[k]) for k in range(a, b)] == ca[2]
+        assert [float(T.nm[k]) for k in range(a, b)] == ca[3]
+    if name == "tiny_edge":
+        assert "edge_noprimary" not in ob.chimeric_alignments and any(T.failed)
+
+
+def test_sa_table_error_semantics():
+    """Unknown SA CIGAR shape -> KeyError (cp:255); zero-length query interval -> ZeroDivisionError (cp:268)."""
+    from coral_amd.chimeric import build_chimeric_table
+    from coral_amd.records import DeviceRecords
+    M, S = 0, 4
+    bad_shape = synth.records_from_alignments([
+        dict(tid=0, pos=10, cigar=[(S, 5), (M, 50)], name="x", sa=[(0, 500, 0, -2, 40, 0, 0, 60, 1)]),
+        dict(tid=0, pos=20, cigar=[(M, 50)], name="y")])
+    with pytest.raises(KeyError):
+        build_chimeric_table(DeviceRecords(bad_shape, "cuda:0"))
+    zero = synth.records_from_alignments([
+        dict(tid=0, pos=10, cigar=[(S, 5), (M, 50)], name="x", sa=[(0, 500, 0, 54, 1, 0, 0, 60, 1)]),     # SM '+': qs=54, qe=rl-1=54
+        dict(tid=0, pos=20, cigar=[(M, 50)], name="y")])
+    with pytest.raises(ZeroDivisionError):
+        build_chimeric_table(DeviceRecords(zero, "cuda:0"))
