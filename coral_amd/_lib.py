@@ -60,6 +60,12 @@ def lib():
                                  C.POINTER(C.c_int32), P]
     L.coral_sa_table.restype = C.c_int
     L.coral_sa_last_error.restype = C.c_char_p
+    L.coral_pyset_batch_create.argtypes = [C.c_int64, P, P, P, C.c_int32, P]
+    L.coral_pyset_batch_create.restype = C.c_void_p
+    L.coral_pyset_union_order.argtypes = [C.c_void_p, C.c_int32, P, P, C.POINTER(C.c_int32)]
+    L.coral_pyset_union_order.restype = C.c_int
+    L.coral_pyset_batch_free.argtypes = [C.c_void_p]
+    L.coral_pyset_batch_free.restype = C.c_int
     L.coral_cluster_first_fit.argtypes = [C.c_int64, P, P, C.c_int64, P, C.POINTER(C.c_int32)]
     L.coral_cluster_first_fit.restype = C.c_int
     L.coral_bam_decode_open.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]

@@ -119,3 +119,139 @@ extern "C" int coral_first_seen_rows(int64_t n, int32_t ncols, const int64_t *ro
     }
     return CORAL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// coral_pyset_* — iteration order of CPython `set` objects, computed without creating them.
+//
+// The reference iterates Python sets of read-name strings inside its interval search
+// (/root/reference/src/infer_breakpoint_graph.py:379-384 builds one set per reached CN segment with .add(),
+// :405-419 unions them with |= into one set per candidate interval, :428/432 iterates that set), and the order of that
+// iteration decides the order of the emitted breakpoints.  To produce the same order at array speed, these functions
+// replay CPython 3.10's set algorithm (Objects/setobject.c: set_add_entry / set_insert_clean / set_table_resize /
+// set_merge; LINEAR_PROBES 9, PERTURB_SHIFT 5, resize at fill*5 >= mask*3 to used*4 (used*2 above 50000), the |=
+// pre-resize to (used + other.used)*2 and its empty-target fast paths) on (item id, hash) pairs.  Item identity stands
+// for string equality.  tests/test_pyset_order.py checks the replay against real sets of str on random inputs.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct PySetEmu {
+    std::vector<int32_t> key;      // item id, -1 = empty slot
+    std::vector<int64_t> hash;
+    size_t mask = 7, fill = 0, used = 0;
+    PySetEmu() : key(8, -1), hash(8, 0) {}
+
+    static void insert_clean(std::vector<int32_t> &k, std::vector<int64_t> &h, size_t mask, int32_t item, int64_t hv) {
+        size_t perturb = (size_t)hv;
+        size_t i = (size_t)hv & mask;
+        for (;;) {
+            size_t e = i;
+            if (k[e] < 0) { k[e] = item; h[e] = hv; return; }
+            if (i + 9 <= mask) {
+                for (int j = 0; j < 9; ++j) {
+                    ++e;
+                    if (k[e] < 0) { k[e] = item; h[e] = hv; return; }
+                }
+            }
+            perturb >>= 5;
+            i = (i * 5 + 1 + perturb) & mask;
+        }
+    }
+    void resize(size_t minused) {
+        size_t newsize = 8;
+        while (newsize <= minused) newsize <<= 1;
+        std::vector<int32_t> nk(newsize, -1);
+        std::vector<int64_t> nh(newsize, 0);
+        const size_t nm = newsize - 1;
+        for (size_t e = 0; e <= mask; ++e)
+            if (key[e] >= 0) insert_clean(nk, nh, nm, key[e], hash[e]);
+        key.swap(nk);
+        hash.swap(nh);
+        mask = nm;
+        fill = used;
+    }
+    void add(int32_t item, int64_t hv) {
+        size_t perturb = (size_t)hv;
+        size_t i = (size_t)hv & mask;
+        for (;;) {
+            size_t e = i;
+            int probes = (i + 9 <= mask) ? 9 : 0;
+            do {
+                if (key[e] < 0) {                      // unused slot (there are never dummies: nothing is deleted)
+                    key[e] = item;
+                    hash[e] = hv;
+                    ++fill;
+                    ++used;
+                    if (fill * 5 >= mask * 3) resize(used > 50000 ? used * 2 : used * 4);
+                    return;
+                }
+                if (hash[e] == hv && key[e] == item) return;       // already present
+                ++e;
+            } while (probes--);
+            perturb >>= 5;
+            i = (i * 5 + 1 + perturb) & mask;
+        }
+    }
+    void merge(const PySetEmu &o) {                    // self |= o
+        if (&o == this || o.used == 0) return;
+        if ((fill + o.used) * 5 >= mask * 3) resize((used + o.used) * 2);
+        if (fill == 0 && mask == o.mask && o.fill == o.used) {
+            key = o.key;
+            hash = o.hash;
+            fill = o.fill;
+            used = o.used;
+            return;
+        }
+        if (fill == 0) {
+            fill = o.used;
+            used = o.used;
+            for (size_t e = 0; e <= o.mask; ++e)
+                if (o.key[e] >= 0) insert_clean(key, hash, mask, o.key[e], o.hash[e]);
+            return;
+        }
+        for (size_t e = 0; e <= o.mask; ++e)
+            if (o.key[e] >= 0) add(o.key[e], o.hash[e]);
+    }
+};
+struct PySetBatch {
+    std::vector<PySetEmu> sets;
+};
+}  // namespace
+
+// One emulated set per key, filled with .add() in entry order (== set([first]) then .add(...), ibg:379-384).
+extern "C" void *coral_pyset_batch_create(int64_t n_entries, const int32_t *key_of_entry, const int32_t *item,
+                                          const int64_t *item_hash, int32_t n_keys, int32_t *out_count) {
+    if (n_entries < 0 || n_keys < 0 || (n_entries > 0 && (!key_of_entry || !item || !item_hash))) return nullptr;
+    PySetBatch *b = new PySetBatch();
+    b->sets.resize((size_t)n_keys);
+    for (int64_t i = 0; i < n_entries; ++i) {
+        const int32_t k = key_of_entry[i];
+        if (k < 0 || k >= n_keys) { delete b; return nullptr; }
+        b->sets[(size_t)k].add(item[i], item_hash[item[i]]);
+    }
+    if (out_count)
+        for (int32_t k = 0; k < n_keys; ++k) out_count[k] = (int32_t)b->sets[(size_t)k].used;
+    return b;
+}
+
+// result = set(); for k in keys: result |= sets[k]; return list(result)      (ibg:405-419 then the iteration at :432)
+extern "C" int coral_pyset_union_order(void *handle, int32_t n_union, const int32_t *keys, int32_t *out_items, int32_t *out_n) {
+    if (!handle || n_union < 0 || (n_union > 0 && !keys) || !out_n) return CORAL_ERR_ARG;
+    PySetBatch *b = (PySetBatch *)handle;
+    PySetEmu acc;
+    for (int32_t j = 0; j < n_union; ++j) {
+        if (keys[j] < 0 || (size_t)keys[j] >= b->sets.size()) return CORAL_ERR_ARG;
+        acc.merge(b->sets[(size_t)keys[j]]);
+    }
+    int32_t n = 0;
+    for (size_t e = 0; e <= acc.mask; ++e)
+        if (acc.key[e] >= 0) {
+            if (out_items) out_items[n] = acc.key[e];
+            ++n;
+        }
+    *out_n = n;
+    return CORAL_OK;
+}
+
+extern "C" int coral_pyset_batch_free(void *handle) {
+    delete (PySetBatch *)handle;
+    return CORAL_OK;
+}

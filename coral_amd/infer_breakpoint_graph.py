@@ -29,7 +29,10 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from . import global_names, kernels
+import ctypes as C
+import os
+
+from . import _lib, global_names, kernels
 from .bpcluster import bpc2bp, cluster_bp_list
 from .breakpoint_graph import (BreakpointGraph, breakpoint_info_text, compute_cn_lr, graph_text,
                                output_breakpoint_graph_lr, output_breakpoint_info_lr)
@@ -37,6 +40,7 @@ from .chimeric import (Candidates, ChimericTable, build_chimeric_table, candidat
 from .global_names import chr_idx
 
 _ORI = "+-"
+_VERIFY_SET_ORDER = os.environ.get("CORAL_VERIFY_SET_ORDER") == "1"     # tests: cross-check the set replay against real sets
 
 
 def _t():
@@ -504,8 +508,14 @@ class bam_to_breakpoint_nanopore():
 
     # -- BFS helpers ---------------------------------------------------------------------------------
     def _reachable_segments(self, chrom, si, ei):
-        """CN segments outside [si, ei] reached from it through chimeric reads, as
-        ``{chr: {cni: set(read names)}}`` with the reference's key and set-insertion order (ibg:369-384)."""
+        """CN segments outside [si, ei] reached from it through chimeric reads (ibg:369-384).
+
+        The reference keeps ``{chr: {cni: set(read names)}}``; here every such set exists only as a native replay of the
+        Python set (coral_pyset_*: same insertion sequence, same str hashes), which yields its size and — after the ``|=``
+        unions of ibg:405-419 — its iteration order as read indices, without creating a single Python object per read.
+        Returns (keys, counts, handle): ``keys`` = {chr: {cni: key id}} in the reference's chromosome-key order,
+        ``counts[key id]`` = distinct reads, ``handle`` for ``_iteration_order`` (free it with ``_free_sets``).
+        """
         T = self._chim
         tid = self._tid_of[chrom]
         if tid not in self._seg_tids:
@@ -514,51 +524,84 @@ class bam_to_breakpoint_nanopore():
         hi = np.searchsorted(self._e_key, tid * (1 << 32) + ei + 1, side="left")
         reads_t = T.read[self._e_row[lo:hi]]            # visiting order: cni ascending, then append order
         if len(reads_t) == 0:
-            return {}
+            return {}, np.zeros(0, dtype=np.int32), None
         u, first = np.unique(reads_t, return_index=True)
         U = u[np.argsort(first, kind="stable")]         # every read once, in first-visit order
         cnt = T.off[U + 1] - T.off[U]
         own = np.repeat(np.arange(len(U)), cnt)
         rows = np.repeat(T.off[U], cnt) + (np.arange(len(own)) - np.repeat(np.cumsum(cnt) - cnt, cnt))
-        return self._reach_dict(U, rows, own, T.tid[rows], tid, si, ei)
-
-    def _reach_dict(self, U, rows, own, t_rows, tid, si, ei):
-        T = self._chim
-        names = self._chim_names
-        chroms = self.rec.header_chroms
+        t_rows = T.tid[rows]
         c0, c1 = T.cni0[rows], T.cni1[rows]
-        v0 = (c0 >= 0) & ((t_rows != tid) | (c0 <= si) | (c0 >= ei))
+        v0 = (c0 >= 0) & ((t_rows != tid) | (c0 <= si) | (c0 >= ei))              # Q9: boundary segments count as outside
         v1 = (c1 >= 0) & (c1 != c0) & ((t_rows != tid) | (c1 <= si) | (c1 >= ei))
         pos = np.arange(len(rows))
         e_pos = np.concatenate([pos[v0], pos[v1]])
+        if len(e_pos) == 0:
+            return {}, np.zeros(0, dtype=np.int32), None
         e_t = np.concatenate([t_rows[v0], t_rows[v1]])
         e_j = np.concatenate([c0[v0], c1[v1]])
-        if len(e_pos) == 0:
-            return {}
-        o = np.argsort(e_pos, kind="stable")           # traversal order: visiting read, then segment
+        o = np.argsort(e_pos, kind="stable")            # traversal order: visiting read, then segment
         e_pos, e_t, e_j = e_pos[o], e_t[o], e_j[o]
         e_read = U[own[e_pos]]
-        # chromosome key order = first appearance
+        code = e_t * (1 << 32) + e_j
+        ukeys, first_k, key_of_entry = np.unique(code, return_index=True, return_inverse=True)
+        # chromosome keys in order of first appearance along the traversal
         ut, ft = np.unique(e_t, return_index=True)
-        chrom_order = ut[np.argsort(ft, kind="stable")]
-        reach: Dict[str, Dict[int, set]] = {}
-        key = e_t * (1 << 32) + e_j
-        ko = np.argsort(key, kind="stable")            # inside a (chr, cni) key: traversal order preserved
-        ks = key[ko]
-        bounds = np.nonzero(np.diff(ks))[0] + 1
-        starts = np.concatenate([[0], bounds])
-        ends = np.concatenate([bounds, [len(ks)]])
-        per_key = {}
-        for s, e in zip(starts, ends):
-            rr = e_read[ko[s:e]]
-            _, f = np.unique(rr, return_index=True)
-            ordered = rr[np.sort(f)]                    # each read once, in first-visit order
-            per_key[int(ks[s])] = set(itemgetter(*ordered.tolist())(names)) if len(ordered) > 1 else set([names[ordered[0]]])
-        for t in chrom_order:
-            reach[chroms[t]] = {}
-        for k, st_ in per_key.items():
-            reach[chroms[k >> 32]][k & 0xFFFFFFFF] = st_
-        return reach
+        chroms = self.rec.header_chroms
+        keys: Dict[str, Dict[int, int]] = {chroms[t]: {} for t in ut[np.argsort(ft, kind="stable")]}
+        for k, cde in enumerate(ukeys.tolist()):
+            keys[chroms[cde >> 32]][cde & 0xFFFFFFFF] = k
+        L = _lib.lib()
+        koe = np.ascontiguousarray(key_of_entry.astype(np.int32))
+        items = np.ascontiguousarray(e_read.astype(np.int32))
+        counts = np.zeros(len(ukeys), dtype=np.int32)
+        hashes = self._read_hashes()
+        handle = L.coral_pyset_batch_create(len(items), koe.ctypes.data, items.ctypes.data, hashes.ctypes.data, len(ukeys),
+                                            counts.ctypes.data)
+        if not handle:
+            raise _lib.CoralHipError("coral_pyset_batch_create failed")
+        if _VERIFY_SET_ORDER:
+            self._verify_sets = (koe, items)
+        return keys, counts, handle
+
+    def _read_hashes(self) -> np.ndarray:
+        """hash(read name) of every chimeric read (index = position in the chimeric table), cached per name id."""
+        T = self._chim
+        if getattr(T, "_hashes", None) is None:
+            dr = self.rec
+            cache = getattr(dr, "_name_hash_cache", None)
+            if cache is None:
+                cache = dr._name_hash_cache = (np.zeros(dr.n_names, dtype=np.int64), np.zeros(dr.n_names, dtype=bool))
+            hv, known = cache
+            ids = T.name_id
+            miss = ids[~known[ids]]
+            if len(miss):
+                names = dr.names
+                hv[miss] = np.fromiter((hash(names[i]) for i in miss.tolist()), dtype=np.int64, count=len(miss))
+                known[miss] = True
+            T._hashes = np.ascontiguousarray(hv[ids])
+        return T._hashes
+
+    def _iteration_order(self, handle, key_ids) -> np.ndarray:
+        """Read indices in the order ``for r in (set() | sets[k0] | sets[k1] | ...)`` would visit them (ibg:405-432)."""
+        L = _lib.lib()
+        k = np.ascontiguousarray(np.asarray(key_ids, dtype=np.int32))
+        out = np.empty(self._chim.n_reads + 1, dtype=np.int32)
+        n = C.c_int32(0)
+        _lib.check(L.coral_pyset_union_order(handle, len(k), k.ctypes.data, out.ctypes.data, C.byref(n)), "coral_pyset_union_order")
+        order = out[:n.value].astype(np.int64)
+        if _VERIFY_SET_ORDER:                      # tests: the replay must equal real sets of str
+            koe, items = self._verify_sets
+            names = self._chim_names
+            acc = set([])
+            for kk in k.tolist():
+                sel = items[koe == kk]
+                s_ = set([names[sel[0]]])
+                for r in sel[1:]:
+                    s_.add(names[r])
+                acc |= s_
+            assert [self._chim_index[nm] for nm in acc] == order.tolist(), "set-order replay diverged from CPython"
+        return order
 
     def find_interval_i(self, ai, ccid):
         """Breadth-first search for intervals connected to interval ``ai`` by breakpoint edges (ibg:343-673)."""
@@ -578,29 +621,29 @@ class bam_to_breakpoint_nanopore():
                 ei = self.pos2cni(chrom, e)[0]
             except Exception:
                 continue
-            reach = self._reachable_segments(chrom, si, ei)
+            reach, counts, set_handle = self._reachable_segments(chrom, si, ei)
             for c in list(reach):
-                for j in [j for j in reach[c] if len(reach[c][j]) < self.min_cluster_cutoff]:
+                for j in [j for j in reach[c] if counts[reach[c][j]] < self.min_cluster_cutoff]:
                     del reach[c][j]
                 if not reach[c]:
                     del reach[c]
             refined, refined_bps = [], []
             for c in reach:
                 bins = sorted(reach[c])
-                groups, names, first = [], set(), 0
+                groups, members, first = [], [], 0      # members: key ids whose sets the reference unions with |=
                 for k in range(len(bins) - 1):
-                    names |= reach[c][bins[k]]
+                    members.append(reach[c][bins[k]])
                     if bins[k + 1] - bins[k] > 2 or by[c][bins[k + 1]][1] - by[c][bins[k]][2] > self.max_seq_len:
-                        groups.append((bins[first], bins[k], names))
+                        groups.append((bins[first], bins[k], members))
                         first = k + 1
-                        names = set()
-                names |= reach[c][bins[-1]]
-                groups.append((bins[first], bins[-1], names))
-                for (b0, b1, grp_names) in groups:
+                        members = []
+                members.append(reach[c][bins[-1]])
+                groups.append((bins[first], bins[-1], members))
+                for (b0, b1, grp_keys) in groups:
                     ns, ne = by[c][b0][1], by[c][b1][2]
                     tgt = [c, ns, ne]
                     here = self.amplicon_intervals[cur]
-                    reads = np.fromiter(map(self._chim_index.__getitem__, grp_names), dtype=np.int64, count=len(grp_names))   # set order (Q21)
+                    reads = self._iteration_order(set_handle, grp_keys)          # set-of-str iteration order (Q21)
                     cands = candidates_between(T, reads, (self._tid_of[c], ns, ne),
                                                (self._tid_of[here[0]], here[1], here[2]), self._chr_rank, self.rec,
                                                self.min_bp_match_cutoff_, 20)
@@ -725,6 +768,8 @@ class bam_to_breakpoint_nanopore():
                         refined.append([f[0], l, r, -1])
                         refined_bps.append([])
 
+            if set_handle:
+                _lib.lib().coral_pyset_batch_free(set_handle)
             conn = self.amplicon_interval_connections
             for ni, cand_iv in enumerate(refined):
                 hit, parts = interval_exclusive(cand_iv, self.amplicon_intervals)

@@ -197,6 +197,19 @@ int coral_cluster_first_fit(int64_t n, const int64_t *p1, const int64_t *p2, int
 int coral_first_seen_rows(int64_t n, int32_t ncols, const int64_t *rows, uint8_t *is_first);
 
 /* ------------------------------------------------------------------------------------------------
+ * coral_pyset_* — HOST functions: the iteration order of the Python sets of read names the reference builds and iterates
+ * in its interval search (/root/reference/src/infer_breakpoint_graph.py:379-384 .add() per reached CN segment,
+ * :405-419 `|=` unions, :428/432 iteration), obtained by replaying CPython 3.10's set algorithm on (item id, str hash)
+ * pairs instead of creating the sets.  `create` builds one set per key from entries in insertion order and reports the
+ * distinct counts; `union_order` returns list(set() | sets[keys[0]] | sets[keys[1]] | ...) as item ids in iteration
+ * order (out_items needs room for the sum of the counts).
+ * ------------------------------------------------------------------------------------------------ */
+void *coral_pyset_batch_create(int64_t n_entries, const int32_t *key_of_entry, const int32_t *item,
+                               const int64_t *item_hash, int32_t n_keys, int32_t *out_count);
+int coral_pyset_union_order(void *handle, int32_t n_union, const int32_t *keys, int32_t *out_items, int32_t *out_n);
+int coral_pyset_batch_free(void *handle);
+
+/* ------------------------------------------------------------------------------------------------
  * coral_bam_decode_* — HOST functions: BAM/BGZF file -> structure-of-arrays records, decoded ONCE.
  *
  * Replaces pysam.AlignmentFile(path, 'rb') + the whole-file fetch() loop

@@ -23,7 +23,7 @@ def test_gpu_matches_reference_golden(case, golden_dir, tmp_path):
 @pytest.mark.skipif(HASHSEED0, reason="already running with PYTHONHASHSEED=0")
 def test_strict_order_in_seeded_subprocess():
     """Byte-identical discordant-edge order needs PYTHONHASHSEED=0 (Appendix A Q21): one child process."""
-    env = dict(os.environ, PYTHONHASHSEED="0")
+    env = dict(os.environ, PYTHONHASHSEED="0", CORAL_VERIFY_SET_ORDER="1")   # also cross-check the native set replay
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-p",
                         "no:cacheprovider", "-k", "golden"], env=env, capture_output=True, text=True, cwd=root)

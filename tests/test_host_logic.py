@@ -20,7 +20,7 @@ def test_host_logic_matches_reference(case, golden_dir, tmp_path, monkeypatch):
 
 @pytest.mark.skipif(HASHSEED0, reason="already running with PYTHONHASHSEED=0")
 def test_strict_order_in_seeded_subprocess():
-    env = dict(os.environ, PYTHONHASHSEED="0")
+    env = dict(os.environ, PYTHONHASHSEED="0", CORAL_VERIFY_SET_ORDER="1")   # also cross-check the native set replay
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, cwd=root)
