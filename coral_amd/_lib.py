@@ -66,6 +66,10 @@ def lib():
     L.coral_pyset_union_order.restype = C.c_int
     L.coral_pyset_batch_free.argtypes = [C.c_void_p]
     L.coral_pyset_batch_free.restype = C.c_int
+    L.coral_reach_create.argtypes = [C.c_int64] + [C.c_void_p] * 6 + [C.c_int64] * 4 + [C.c_void_p, C.c_void_p]
+    L.coral_reach_create.restype = C.c_void_p
+    L.coral_reach_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.coral_reach_keys.restype = C.c_int
     L.coral_cluster_first_fit.argtypes = [C.c_int64, P, P, C.c_int64, P, C.POINTER(C.c_int32)]
     L.coral_cluster_first_fit.restype = C.c_int
     L.coral_bam_decode_open.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]

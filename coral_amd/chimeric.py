@@ -67,7 +67,7 @@ def build_chimeric_table(dr) -> ChimericTable:
     T.read_length = rl
     T.name_id, T.failed, T.off = name_id, failed, off
     r64 = rows.astype(np.int64)
-    T.qs, T.qe, T.tid, T.ra, T.rb, T.strand, T.mapq = (r64[:, k] for k in range(7))
+    T.qs, T.qe, T.tid, T.ra, T.rb, T.strand, T.mapq = (np.ascontiguousarray(r64[:, k]) for k in range(7))
     T.read = np.repeat(np.arange(len(name_id), dtype=np.int64), np.diff(off))
     T.nm = r64[:, 7].astype(np.float64) / (T.qe - T.qs) if len(r64) else np.zeros(0)
     T.cni0 = np.full(len(r64), -1, dtype=np.int64)

@@ -213,6 +213,7 @@ struct PySetEmu {
 };
 struct PySetBatch {
     std::vector<PySetEmu> sets;
+    virtual ~PySetBatch() {}
 };
 }  // namespace
 
@@ -253,5 +254,64 @@ extern "C" int coral_pyset_union_order(void *handle, int32_t n_union, const int3
 
 extern "C" int coral_pyset_batch_free(void *handle) {
     delete (PySetBatch *)handle;
+    return CORAL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Reachable CN segments of one amplicon interval (ibg:369-384): walk the reads hashed to segments [si, ei] of `tid` in
+// visiting order, and add every read to the emulated set of each (chromosome, segment) it touches outside the interval.
+// Keys are numbered in order of first appearance, which is the insertion order of the reference's nested dicts.
+namespace {
+struct ReachSets : PySetBatch {
+    std::vector<int64_t> codes;      // tid << 32 | cni per key
+};
+}  // namespace
+
+extern "C" void *coral_reach_create(int64_t n_visit, const int64_t *visit_rows, const int64_t *row_read, const int64_t *off,
+                                    const int64_t *row_tid, const int64_t *cni0, const int64_t *cni1, int64_t n_reads,
+                                    int64_t tid, int64_t si, int64_t ei, const int64_t *read_hash, int32_t *n_keys_out) {
+    if (n_visit < 0 || n_reads < 0 || !n_keys_out || (n_visit > 0 && (!visit_rows || !row_read || !off || !row_tid || !cni0 ||
+                                                                       !cni1 || !read_hash)))
+        return nullptr;
+    ReachSets *b = new ReachSets();
+    std::vector<uint8_t> seen((size_t)n_reads, 0);
+    std::unordered_map<int64_t, int32_t> key_of;
+    auto emit = [&](int64_t t, int64_t c, int64_t r) {
+        const int64_t code = (t << 32) | c;
+        auto it = key_of.find(code);
+        int32_t k;
+        if (it == key_of.end()) {
+            k = (int32_t)b->sets.size();
+            key_of.emplace(code, k);
+            b->sets.emplace_back();
+            b->codes.push_back(code);
+        } else {
+            k = it->second;
+        }
+        b->sets[(size_t)k].add((int32_t)r, read_hash[r]);
+    };
+    for (int64_t v = 0; v < n_visit; ++v) {
+        const int64_t r = row_read[visit_rows[v]];
+        if (r < 0 || r >= n_reads) { delete b; return nullptr; }
+        if (seen[(size_t)r]) continue;
+        seen[(size_t)r] = 1;
+        for (int64_t k = off[r]; k < off[r + 1]; ++k) {
+            const int64_t t = row_tid[k], c0 = cni0[k], c1 = cni1[k];
+            const bool other = t != tid;
+            if (c0 >= 0 && (other || c0 <= si || c0 >= ei)) emit(t, c0, r);               // Q9: boundary segments count as outside
+            if (c1 >= 0 && c1 != c0 && (other || c1 <= si || c1 >= ei)) emit(t, c1, r);
+        }
+    }
+    *n_keys_out = (int32_t)b->sets.size();
+    return static_cast<PySetBatch *>(b);
+}
+
+extern "C" int coral_reach_keys(void *handle, int64_t *codes, int32_t *counts) {
+    if (!handle || !codes || !counts) return CORAL_ERR_ARG;
+    ReachSets *b = static_cast<ReachSets *>((PySetBatch *)handle);
+    for (size_t k = 0; k < b->sets.size(); ++k) {
+        codes[k] = b->codes[k];
+        counts[k] = (int32_t)b->sets[k].used;
+    }
     return CORAL_OK;
 }

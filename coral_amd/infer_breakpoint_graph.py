@@ -88,7 +88,15 @@ class _ChimericAlignments(dict):
     def __init__(self, owner, names_in_order):
         super().__init__(dict.fromkeys(names_in_order))
         self._owner = owner
-        self._index = {nm: k for k, nm in enumerate(names_in_order)}
+        self._names = names_in_order
+        self._index_ = None
+        self._made = []                      # keys holding a materialised value
+
+    @property
+    def _index(self):
+        if self._index_ is None:
+            self._index_ = {nm: k for k, nm in enumerate(self._names)}
+        return self._index_
 
     def _make(self, key):
         o = self._owner
@@ -114,6 +122,7 @@ class _ChimericAlignments(dict):
         if v is None:
             v = self._make(key)
             dict.__setitem__(self, key, v)
+            self._made.append(key)
         return v
 
     def get(self, key, default=None):
@@ -129,8 +138,10 @@ class _ChimericAlignments(dict):
         dict.__delitem__(self, key)
 
     def invalidate(self):
-        for k in dict.keys(self):
-            dict.__setitem__(self, k, None)
+        for k in self._made:
+            if dict.__contains__(self, k):
+                dict.__setitem__(self, k, None)
+        self._made = []
 
 
 class _RecordsFile:
@@ -317,9 +328,8 @@ class bam_to_breakpoint_nanopore():
         names = self.rec.names
         has = np.nonzero(T.read_length >= 0)[0]
         self.read_length = _LazyReadLength(names, T.read_length, has)
-        self._chim_names = [names[i] for i in T.name_id]
+        self._chim_names = self._names_of(T.name_id)
         self.chimeric_alignments = _ChimericAlignments(self, self._chim_names)
-        self._chim_index = self.chimeric_alignments._index
         logging.info(_t() + "Fetched %d chimeric reads." % (len(self.chimeric_alignments)))
         logging.info(_t() + "Computed alignment intervals on all chimeric reads.")
 
@@ -514,7 +524,7 @@ class bam_to_breakpoint_nanopore():
         Python set (coral_pyset_*: same insertion sequence, same str hashes), which yields its size and — after the ``|=``
         unions of ibg:405-419 — its iteration order as read indices, without creating a single Python object per read.
         Returns (keys, counts, handle): ``keys`` = {chr: {cni: key id}} in the reference's chromosome-key order,
-        ``counts[key id]`` = distinct reads, ``handle`` for ``_iteration_order`` (free it with ``_free_sets``).
+        ``counts[key id]`` = distinct reads, ``handle`` for ``_iteration_order`` (freed by the caller).
         """
         T = self._chim
         tid = self._tid_of[chrom]
@@ -522,47 +532,59 @@ class bam_to_breakpoint_nanopore():
             raise KeyError(chrom)                       # self.chimeric_alignments_seg[chr] at ibg:371
         lo = np.searchsorted(self._e_key, tid * (1 << 32) + si, side="left")
         hi = np.searchsorted(self._e_key, tid * (1 << 32) + ei + 1, side="left")
-        reads_t = T.read[self._e_row[lo:hi]]            # visiting order: cni ascending, then append order
-        if len(reads_t) == 0:
+        visit = np.ascontiguousarray(self._e_row[lo:hi])  # visiting order: cni ascending, then append order
+        if len(visit) == 0:
             return {}, np.zeros(0, dtype=np.int32), None
-        u, first = np.unique(reads_t, return_index=True)
-        U = u[np.argsort(first, kind="stable")]         # every read once, in first-visit order
-        cnt = T.off[U + 1] - T.off[U]
-        own = np.repeat(np.arange(len(U)), cnt)
-        rows = np.repeat(T.off[U], cnt) + (np.arange(len(own)) - np.repeat(np.cumsum(cnt) - cnt, cnt))
-        t_rows = T.tid[rows]
-        c0, c1 = T.cni0[rows], T.cni1[rows]
-        v0 = (c0 >= 0) & ((t_rows != tid) | (c0 <= si) | (c0 >= ei))              # Q9: boundary segments count as outside
-        v1 = (c1 >= 0) & (c1 != c0) & ((t_rows != tid) | (c1 <= si) | (c1 >= ei))
-        pos = np.arange(len(rows))
-        e_pos = np.concatenate([pos[v0], pos[v1]])
-        if len(e_pos) == 0:
-            return {}, np.zeros(0, dtype=np.int32), None
-        e_t = np.concatenate([t_rows[v0], t_rows[v1]])
-        e_j = np.concatenate([c0[v0], c1[v1]])
-        o = np.argsort(e_pos, kind="stable")            # traversal order: visiting read, then segment
-        e_pos, e_t, e_j = e_pos[o], e_t[o], e_j[o]
-        e_read = U[own[e_pos]]
-        code = e_t * (1 << 32) + e_j
-        ukeys, first_k, key_of_entry = np.unique(code, return_index=True, return_inverse=True)
-        # chromosome keys in order of first appearance along the traversal
-        ut, ft = np.unique(e_t, return_index=True)
-        chroms = self.rec.header_chroms
-        keys: Dict[str, Dict[int, int]] = {chroms[t]: {} for t in ut[np.argsort(ft, kind="stable")]}
-        for k, cde in enumerate(ukeys.tolist()):
-            keys[chroms[cde >> 32]][cde & 0xFFFFFFFF] = k
         L = _lib.lib()
-        koe = np.ascontiguousarray(key_of_entry.astype(np.int32))
-        items = np.ascontiguousarray(e_read.astype(np.int32))
-        counts = np.zeros(len(ukeys), dtype=np.int32)
         hashes = self._read_hashes()
-        handle = L.coral_pyset_batch_create(len(items), koe.ctypes.data, items.ctypes.data, hashes.ctypes.data, len(ukeys),
-                                            counts.ctypes.data)
+        nk = C.c_int32(0)
+        handle = L.coral_reach_create(len(visit), visit.ctypes.data, T.read.ctypes.data, T.off.ctypes.data, T.tid.ctypes.data,
+                                      T.cni0.ctypes.data, T.cni1.ctypes.data, T.n_reads, tid, si, ei, hashes.ctypes.data,
+                                      C.byref(nk))
         if not handle:
-            raise _lib.CoralHipError("coral_pyset_batch_create failed")
+            raise _lib.CoralHipError("coral_reach_create failed")
+        codes = np.empty(nk.value, dtype=np.int64)
+        counts = np.empty(nk.value, dtype=np.int32)
+        _lib.check(L.coral_reach_keys(handle, codes.ctypes.data, counts.ctypes.data), "coral_reach_keys")
+        chroms = self.rec.header_chroms
+        keys: Dict[str, Dict[int, int]] = {}
+        for k, cde in enumerate(codes.tolist()):
+            keys.setdefault(chroms[cde >> 32], {})[cde & 0xFFFFFFFF] = k
         if _VERIFY_SET_ORDER:
-            self._verify_sets = (koe, items)
+            self._verify_reach(tid, si, ei, visit, keys, counts)
         return keys, counts, handle
+
+    def _verify_reach(self, tid, si, ei, visit, keys, counts):
+        """Tests only: the traversal of ibg:369-384 with real sets of str, compared with the native result."""
+        T = self._chim
+        names, chroms = self._chim_names, self.rec.header_chroms
+        real: Dict[str, Dict[int, set]] = {}
+        done = set()
+        for row in visit.tolist():
+            r = int(T.read[row])
+            if r in done:
+                continue
+            done.add(r)
+            for k in range(int(T.off[r]), int(T.off[r + 1])):
+                cand = []
+                c0, c1, t = int(T.cni0[k]), int(T.cni1[k]), int(T.tid[k])
+                if c0 >= 0:
+                    cand.append(c0)
+                if c1 >= 0 and c1 != c0:
+                    cand.append(c1)
+                for cni in cand:
+                    if t != tid or cni <= si or cni >= ei:
+                        d = real.setdefault(chroms[t], {})
+                        if cni in d:
+                            d[cni].add(names[r])
+                        else:
+                            d[cni] = set([names[r]])
+        assert list(real) == list(keys), "chromosome order of the reachable segments diverged"
+        for c in real:
+            assert set(real[c]) == set(keys[c])
+            for cni, s_ in real[c].items():
+                assert counts[keys[c][cni]] == len(s_)
+        self._verify_sets = real, keys
 
     def _read_hashes(self) -> np.ndarray:
         """hash(read name) of every chimeric read (index = position in the chimeric table), cached per name id."""
@@ -586,21 +608,19 @@ class bam_to_breakpoint_nanopore():
         """Read indices in the order ``for r in (set() | sets[k0] | sets[k1] | ...)`` would visit them (ibg:405-432)."""
         L = _lib.lib()
         k = np.ascontiguousarray(np.asarray(key_ids, dtype=np.int32))
-        out = np.empty(self._chim.n_reads + 1, dtype=np.int32)
+        out = getattr(self._chim, "_order_buf", None)
+        if out is None:
+            out = self._chim._order_buf = np.empty(self._chim.n_reads + 1, dtype=np.int32)
         n = C.c_int32(0)
         _lib.check(L.coral_pyset_union_order(handle, len(k), k.ctypes.data, out.ctypes.data, C.byref(n)), "coral_pyset_union_order")
         order = out[:n.value].astype(np.int64)
         if _VERIFY_SET_ORDER:                      # tests: the replay must equal real sets of str
-            koe, items = self._verify_sets
-            names = self._chim_names
+            real, keys = self._verify_sets
+            by_id = {kid: real[c][cni] for c in keys for cni, kid in keys[c].items()}
             acc = set([])
             for kk in k.tolist():
-                sel = items[koe == kk]
-                s_ = set([names[sel[0]]])
-                for r in sel[1:]:
-                    s_.add(names[r])
-                acc |= s_
-            assert [self._chim_index[nm] for nm in acc] == order.tolist(), "set-order replay diverged from CPython"
+                acc |= by_id[kk]
+            assert [self.chimeric_alignments._index[nm] for nm in acc] == order.tolist(), "set-order replay diverged from CPython"
         return order
 
     def find_interval_i(self, ai, ccid):
@@ -953,14 +973,16 @@ class bam_to_breakpoint_nanopore():
             pts += [(t1, e[1]), (t2, e[4]), (t1, e[1] - cut - 1), (t2, e[4] + cut)]
         cover = kernels.point_cover(self.rec, pts) if pts else []
         nid = self.rec.h_name_id
-        names = self.rec.names
+        edge_names: Dict[tuple, set] = {}          # read names supporting a discordant edge (membership tests only)
         for q, (g, e) in enumerate(edges):
             rls, rrs, rls1, rrs1 = (np.unique(nid[cover[4 * q + d]]) for d in range(4))
             rbps = set()
             for node in ((e[0], e[1], e[2]), (e[3], e[4], e[5])):
                 for k in g.nodes[node][2]:
-                    for t in g.discordant_edges[k][10]:
-                        rbps.add(t[0])
+                    key = (id(g), k)
+                    if key not in edge_names:
+                        edge_names[key] = {t[0] for t in g.discordant_edges[k][10]}
+                    rbps |= edge_names[key]
             both = np.intersect1d(np.intersect1d(rls, rrs, assume_unique=True),
                                   np.intersect1d(rls1, rrs1, assume_unique=True), assume_unique=True)
             e[9] = set(self._names_of(np.union1d(rls, rrs)))

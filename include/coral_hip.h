@@ -209,6 +209,19 @@ void *coral_pyset_batch_create(int64_t n_entries, const int32_t *key_of_entry, c
 int coral_pyset_union_order(void *handle, int32_t n_union, const int32_t *keys, int32_t *out_items, int32_t *out_n);
 int coral_pyset_batch_free(void *handle);
 
+/* Reachable CN segments of one amplicon interval — the traversal of ibg:369-384 with the read-name sets replayed natively.
+ * visit_rows[n_visit]: rows of the chimeric table hashed to segments si..ei of chromosome `tid`, in the reference's visiting
+ * order (segment ascending, then append order).  row_read/row_tid/cni0/cni1 are per table row, off[n_reads + 1] the row
+ * ranges per read, read_hash[n_reads] = hash(read name).  Every read is expanded once (first visit); it is added to the set
+ * of each (chromosome, segment) it touches outside (si, ei) on `tid` (boundary segments count as outside, Appendix A Q9).
+ * Returns a handle usable with coral_pyset_union_order / coral_pyset_batch_free (NULL on bad arguments); keys are numbered
+ * in order of first appearance = insertion order of the reference's nested dicts. */
+void *coral_reach_create(int64_t n_visit, const int64_t *visit_rows, const int64_t *row_read, const int64_t *off,
+                         const int64_t *row_tid, const int64_t *cni0, const int64_t *cni1, int64_t n_reads, int64_t tid,
+                         int64_t si, int64_t ei, const int64_t *read_hash, int32_t *n_keys_out);
+/* codes[k] = tid << 32 | segment index, counts[k] = distinct reads of key k. */
+int coral_reach_keys(void *handle, int64_t *codes, int32_t *counts);
+
 /* ------------------------------------------------------------------------------------------------
  * coral_bam_decode_* — HOST functions: BAM/BGZF file -> structure-of-arrays records, decoded ONCE.
  *
