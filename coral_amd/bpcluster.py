@@ -138,3 +138,39 @@ def bpc2bp(c: Candidates, idx: np.ndarray, cutoff: int):
     st[2] = _sigma(st[2], st[0])
     st[3] = _sigma(st[3], st[1])
     return bp1, bp2, sup, st, idx[~ok]
+
+
+def call_breakpoints(c: Candidates, min_cluster_cutoff: float, bp_distance_cutoff: int, match_cutoff: int, accept_floor: float,
+                     advance_subcluster: bool):
+    """cluster_bp_list + the sub-cluster loop around bpc2bp in one native call (coral_call_breakpoints).
+
+    Returns (cluster sizes, calls) with calls = [(head index, p1, p2, support index array, stats list)], in the reference's
+    order; the functions above are the same algorithm step by step (kept for the unit vectors and as documentation).
+    """
+    n = len(c)
+    if n == 0:
+        return [], []
+    cols = [getattr(c, k) for k in Candidates.FIELDS]
+    ptrs = (C.c_void_p * 13)(*[a.ctypes.data for a in cols])
+    strides = (C.c_int64 * 13)(*[a.strides[0] // 8 for a in cols])
+    n_cl, n_calls = C.c_int32(0), C.c_int32(0)
+    cluster_size = np.empty(n, dtype=np.int32)
+    head, p1, p2 = (np.empty(n, dtype=np.int64) for _ in range(3))
+    stats = np.empty(6 * n, dtype=np.float64)
+    flags = np.empty(n, dtype=np.int32)
+    sup_off = np.empty(n + 1, dtype=np.int64)
+    sup_idx = np.empty(n, dtype=np.int64)
+    _lib.check(_lib.lib().coral_call_breakpoints(
+        n, ptrs, strides, float(min_cluster_cutoff), int(bp_distance_cutoff), int(match_cutoff), float(accept_floor),
+        1 if advance_subcluster else 0, C.byref(n_cl), cluster_size.ctypes.data, C.byref(n_calls), head.ctypes.data,
+        p1.ctypes.data, p2.ctypes.data, stats.ctypes.data, flags.ctypes.data, sup_off.ctypes.data, sup_idx.ctypes.data),
+        "coral_call_breakpoints")
+    calls = []
+    for k in range(n_calls.value):
+        st = stats[6 * k:6 * k + 6].tolist()
+        if flags[k] & 1:
+            st[2] = 0                                     # the reference's ValueError branch stores the integer 0
+        if flags[k] & 2:
+            st[3] = 0
+        calls.append((int(head[k]), int(p1[k]), int(p2[k]), sup_idx[sup_off[k]:sup_off[k + 1]], st))
+    return cluster_size[:n_cl.value].tolist(), calls

@@ -33,7 +33,7 @@ import ctypes as C
 import os
 
 from . import _lib, global_names, kernels
-from .bpcluster import bpc2bp, cluster_bp_list
+from .bpcluster import call_breakpoints, bpc2bp, cluster_bp_list
 from .breakpoint_graph import (BreakpointGraph, breakpoint_info_text, compute_cn_lr, graph_text,
                                output_breakpoint_graph_lr, output_breakpoint_info_lr)
 from .chimeric import (Candidates, ChimericTable, build_chimeric_table, candidates_between, candidates_within)
@@ -209,6 +209,7 @@ class bam_to_breakpoint_nanopore():
         self.normal_cov = 0.0
         self.ccid2id = dict()
         self.new_bp_list = []
+        self._bp_name_ids: Dict[int, list] = {}     # id(support set) -> [name id arrays]; see addbp
         self.new_bp_stats = []
         self.new_bp_ccids = []
         self.source_edges = []
@@ -464,13 +465,24 @@ class bam_to_breakpoint_nanopore():
                         queue.append(p)
         logging.debug(_t() + "There are %d amplicon intervals after merging." % len(self.amplicon_intervals))
 
-    def addbp(self, bp_, bpr_, bp_stats_, ccid):
-        """Append a breakpoint, or merge its reads into the first one within 200 bp at both ends (ibg:326-340)."""
+    def addbp(self, bp_, bpr_, bp_stats_, ccid, name_ids=None):
+        """Append a breakpoint, or merge its reads into the first one within 200 bp at both ends (ibg:326-340).
+
+        ``name_ids`` (optional) = name ids of the reads in ``bpr_``; kept beside the set (keyed by the set object, which is the
+        one the graph's discordant edge ends up holding) so that assign_cov can test membership on integer arrays."""
         for k, bp in enumerate(self.new_bp_list):
             if bp[0] == bp_[0] and bp[3] == bp_[3] and bp[2] == bp_[2] and bp[5] == bp_[5] and \
                     abs(bp[1] - bp_[1]) < 200 and abs(bp[4] - bp_[4]) < 200:
                 bp[-1] |= set(bpr_)
+                ids = self._bp_name_ids.get(id(bp[-1]))
+                if ids is not None:
+                    if name_ids is None:
+                        del self._bp_name_ids[id(bp[-1])]
+                    else:
+                        ids.append(name_ids)
                 return k
+        if name_ids is not None:
+            self._bp_name_ids[id(bpr_)] = [name_ids]
         self.new_bp_list.append(bp_ + [bpr_])
         self.new_bp_ccids.append(ccid)
         self.new_bp_stats.append(bp_stats_)
@@ -497,24 +509,15 @@ class bam_to_breakpoint_nanopore():
         """
         chroms = self.rec.header_chroms
         floor = max(self.normal_cov * self.min_bp_cov_factor, 3.0)
-        for cl in cluster_bp_list(c, self.min_cluster_cutoff, self.max_breakpoint_distance_cutoff):
-            logging.debug(_t() + "New cluster of size %d." % (len(cl)))
-            if len(cl) < self.min_cluster_cutoff:
-                continue
-            sub = 0
-            rest = cl
-            while len(rest) >= self.min_cluster_cutoff:
-                head = rest[0]
-                p1, p2, sup, st, rest = bpc2bp(c, rest, self.min_bp_match_cutoff_)
-                tuples = self._read_tuples(c, sup)
-                n_sup = len(set(tuples))
-                if (sub == 0 and n_sup >= self.min_cluster_cutoff) or n_sup >= floor:
-                    bp = [chroms[c.c1[head]], p1, _ORI[c.o1[head]], chroms[c.c2[head]], p2, _ORI[c.o2[head]],
-                          (self.rec.names[c.read[head]], int(c.i[head]), int(c.j[head])), int(c.gap[head]),
-                          int(c.swapped[head])]
-                    yield bp, tuples, st
-                if advance_subcluster:
-                    sub += 1
+        sizes, calls = call_breakpoints(c, self.min_cluster_cutoff, self.max_breakpoint_distance_cutoff,
+                                        self.min_bp_match_cutoff_, floor, advance_subcluster)
+        if logging.getLogger().isEnabledFor(logging.DEBUG):
+            for sz in sizes:
+                logging.debug(_t() + "New cluster of size %d." % sz)
+        for head, p1, p2, sup, st in calls:
+            bp = [chroms[c.c1[head]], p1, _ORI[c.o1[head]], chroms[c.c2[head]], p2, _ORI[c.o2[head]],
+                  (self.rec.names[c.read[head]], int(c.i[head]), int(c.j[head])), int(c.gap[head]), int(c.swapped[head])]
+            yield bp, self._read_tuples(c, sup), st, c.read[sup]
 
     # -- BFS helpers ---------------------------------------------------------------------------------
     def _reachable_segments(self, chrom, si, ei):
@@ -670,8 +673,8 @@ class bam_to_breakpoint_nanopore():
                     cands.read = T.name_id[cands.read]
                     logging.debug(_t() + "\t\tFound %d reads connecting the two intervals." % len(cands))
                     found = []
-                    for bp, tuples, st in self._call_breakpoints(cands, advance_subcluster=False):
-                        k = self.addbp(bp, set(tuples), st, ccid)
+                    for bp, tuples, st, ids in self._call_breakpoints(cands, advance_subcluster=False):
+                        k = self.addbp(bp, set(tuples), st, ccid, ids)
                         if k not in found:
                             found.append(k)
                     inside, outside = [], []
@@ -824,12 +827,12 @@ class bam_to_breakpoint_nanopore():
 
     def _add_clustered(self, cands: Candidates):
         """Tail shared by find_breakpoints and find_smalldel_breakpoints (ibg:691-718, ibg:775-802)."""
-        for bp, tuples, st in self._call_breakpoints(cands, advance_subcluster=True):
+        for bp, tuples, st, ids in self._call_breakpoints(cands, advance_subcluster=True):
             io1 = interval_overlap_l([bp[0], bp[1], bp[1]], self.amplicon_intervals)
             io2 = interval_overlap_l([bp[3], bp[4], bp[4]], self.amplicon_intervals)
             if io1 >= 0 and io2 >= 0:
                 assert self.amplicon_intervals[io1][3] == self.amplicon_intervals[io2][3]
-                k = self.addbp(bp, set(tuples), st, self.amplicon_intervals[io1][3])
+                k = self.addbp(bp, set(tuples), st, self.amplicon_intervals[io1][3], ids)
                 self.amplicon_interval_connections.setdefault((min(io1, io2), max(io1, io2)), set()).add(k)
 
     # ---- A6 ----------------------------------------------------------------------------------
@@ -973,20 +976,25 @@ class bam_to_breakpoint_nanopore():
             pts += [(t1, e[1]), (t2, e[4]), (t1, e[1] - cut - 1), (t2, e[4] + cut)]
         cover = kernels.point_cover(self.rec, pts) if pts else []
         nid = self.rec.h_name_id
-        edge_names: Dict[tuple, set] = {}          # read names supporting a discordant edge (membership tests only)
+        edge_names: Dict[int, set] = {}            # read names of a support set without name ids (membership tests only)
         for q, (g, e) in enumerate(edges):
             rls, rrs, rls1, rrs1 = (np.unique(nid[cover[4 * q + d]]) for d in range(4))
-            rbps = set()
-            for node in ((e[0], e[1], e[2]), (e[3], e[4], e[5])):
-                for k in g.nodes[node][2]:
-                    key = (id(g), k)
-                    if key not in edge_names:
-                        edge_names[key] = {t[0] for t in g.discordant_edges[k][10]}
-                    rbps |= edge_names[key]
+            support = [g.discordant_edges[k][10] for node in ((e[0], e[1], e[2]), (e[3], e[4], e[5])) for k in g.nodes[node][2]]
             both = np.intersect1d(np.intersect1d(rls, rrs, assume_unique=True),
                                   np.intersect1d(rls1, rrs1, assume_unique=True), assume_unique=True)
             e[9] = set(self._names_of(np.union1d(rls, rrs)))
-            e[8] = sum(1 for nm in self._names_of(both) if nm not in rbps) if rbps else int(len(both))
+            id_lists = [self._bp_name_ids.get(id(s_)) for s_ in support]
+            if not support:
+                e[8] = int(len(both))
+            elif all(x is not None for x in id_lists):        # name ids of every supporting set are at hand
+                e[8] = int(len(both) - np.isin(both, np.concatenate([a for x in id_lists for a in x])).sum())
+            else:
+                rbps = set()
+                for s_ in support:
+                    if id(s_) not in edge_names:
+                        edge_names[id(s_)] = {t[0] for t in s_}
+                    rbps |= edge_names[id(s_)]
+                e[8] = sum(1 for nm in self._names_of(both) if nm not in rbps)
 
     # ---- SURVEY.md §8(f) item 2 -------------------------------------------------------------------
     def compute_path_constraints(self):

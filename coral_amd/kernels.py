@@ -198,17 +198,23 @@ def _bp_candidates_local(dr, T, sel, mode: int, intervals, chr_rank, cutoff: int
     off, qs, qe, tid, ra, rb, strand, mapq = T.device_arrays(dev)
     ct = _lib.coral_chimeric_t(T.n_reads, off.data_ptr(), qs.data_ptr(), qe.data_ptr(), tid.data_ptr(), ra.data_ptr(),
                                rb.data_ptr(), strand.data_ptr(), mapq.data_ptr())
-    sel_t = None if sel is None else torch.from_numpy(np.ascontiguousarray(np.asarray(sel, dtype=np.int32))).to(dev)
+    # one upload for all small inputs: [selection | interval tid | start | end | chromosome ranks]
     iv = np.asarray(intervals, dtype=np.int32).reshape(-1, 3)
-    it, is_, ie = (torch.from_numpy(np.ascontiguousarray(iv[:, k])).to(dev) for k in range(3))
-    cr = torch.from_numpy(np.ascontiguousarray(np.asarray(chr_rank, dtype=np.int32))).to(dev)
+    parts = [] if sel is None else [np.asarray(sel, dtype=np.int32)]
+    parts += [iv[:, 0], iv[:, 1], iv[:, 2], np.asarray(chr_rank, dtype=np.int32)]
+    packed = torch.from_numpy(np.concatenate(parts)).to(dev)
+    at = packed.data_ptr()
+    sel_ptr = None
+    if sel is not None:
+        sel_ptr = at
+        at += 4 * n_sel
+    it_ptr, is_ptr, ie_ptr, cr_ptr = at, at + 4 * len(iv), at + 8 * len(iv), at + 12 * len(iv)
     counts = torch.empty(n_sel + 2, dtype=torch.int32, device=dev)
     cap = max(1024, 2 * n_sel)
     while True:
         cand = torch.empty((cap, 13), dtype=torch.int32, device=dev)
         n_out = C.c_int32(0)
-        rc = L.coral_bp_candidates(C.byref(ct), n_sel, None if sel_t is None else sel_t.data_ptr(), mode, len(iv),
-                                   it.data_ptr(), is_.data_ptr(), ie.data_ptr(), cr.data_ptr(), len(chr_rank), cutoff,
+        rc = L.coral_bp_candidates(C.byref(ct), n_sel, sel_ptr, mode, len(iv), it_ptr, is_ptr, ie_ptr, cr_ptr, len(chr_rank), cutoff,
                                    min_mapq, gap_, gap_mapq, counts.data_ptr(), cand.data_ptr(), cap, C.byref(n_out),
                                    dr.stream())
         if rc == -3:                      # CORAL_ERR_CAPACITY

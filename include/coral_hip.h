@@ -209,6 +209,22 @@ void *coral_pyset_batch_create(int64_t n_entries, const int32_t *key_of_entry, c
 int coral_pyset_union_order(void *handle, int32_t n_union, const int32_t *keys, int32_t *out_items, int32_t *out_n);
 int coral_pyset_batch_free(void *handle);
 
+/* Candidates -> clusters -> exact breakpoints in one call: cluster_bp_list (bu:252-286), then for every cluster the
+ * sub-cluster loop of ibg:436-457 / :693-718 / :777-802 around bpc2bp (bu:299-388) and bp_match (bu:391-416).
+ * field_ptr[13] / field_stride[13] (stride in elements): the candidate columns c1, p1, o1, c2, p2, o2, read, i, j, gap,
+ * swapped, mapq_a, mapq_b as int64 (chromosomes as BAM tids < 64, orientation 0 '+' / 1 '-').
+ * min_cluster_cutoff: minimum cluster size and first-sub-cluster support; accept_floor: support needed by later sub-clusters
+ * (max(normal_cov * min_bp_cov_factor, 3)); advance_subcluster = 0 reproduces the BFS call site, which never increments its
+ * sub-cluster counter (Appendix A Q4).
+ * Outputs (caller allocates n entries each, call_sup_off n + 1, call_stats 6 n): cluster_size[*n_clusters] for the log;
+ * for each accepted breakpoint k < *n_calls: call_head (candidate whose fields name the breakpoint), call_p1/p2 (positions),
+ * call_stats[6k..] (mean p1, mean p2, sd p1, sd p2, mean mapq 1, mean mapq 2), call_flags bit0/bit1 = the sd was the
+ * reference's "ValueError -> integer 0" case, and sup_idx[call_sup_off[k] .. call_sup_off[k+1]) = supporting candidates. */
+int coral_call_breakpoints(int64_t n, const int64_t *const *field_ptr, const int64_t *field_stride, double min_cluster_cutoff,
+                           int64_t bp_distance_cutoff, int64_t match_cutoff, double accept_floor, int32_t advance_subcluster,
+                           int32_t *n_clusters, int32_t *cluster_size, int32_t *n_calls, int64_t *call_head, int64_t *call_p1,
+                           int64_t *call_p2, double *call_stats, int32_t *call_flags, int64_t *call_sup_off, int64_t *sup_idx);
+
 /* Reachable CN segments of one amplicon interval — the traversal of ibg:369-384 with the read-name sets replayed natively.
  * visit_rows[n_visit]: rows of the chimeric table hashed to segments si..ei of chromosome `tid`, in the reference's visiting
  * order (segment ascending, then append order).  row_read/row_tid/cni0/cni1 are per table row, off[n_reads + 1] the row
