@@ -38,13 +38,60 @@ inline bool sigma(double sq_mean, double mean, double *out) {
 }
 
 // Unique mode, else the median rounded toward the junction side of the last cluster member (bu:336-357, Appendix A Q6).
-int64_t consensus(std::vector<int64_t> &v, bool last_is_plus) {
+// Values of one cluster lie within a few hundred bp of each other, so they are counted in a small table; a wide spread
+// falls back to sorting.  Both give the same mode / tie / median.
+int64_t consensus(std::vector<int64_t> &v, bool last_is_plus, std::vector<int32_t> &count) {
+    const size_t n = v.size();
+    int64_t lo = v[0], hi = v[0];
+    for (int64_t x : v) {
+        lo = std::min(lo, x);
+        hi = std::max(hi, x);
+    }
+    auto round_median = [&](int64_t a, int64_t b) {
+        const double med = ((double)a + (double)b) / 2.0;
+        return (int64_t)(last_is_plus ? ceil(med) : floor(med));
+    };
+    if (hi - lo < 8192) {
+        count.assign((size_t)(hi - lo + 1), 0);
+        for (int64_t x : v) ++count[(size_t)(x - lo)];
+        int32_t top = 0;
+        size_t n_top = 0, n_unique = 0, mode = 0;
+        for (size_t k = 0; k < count.size(); ++k) {
+            if (!count[k]) continue;
+            ++n_unique;
+            if (count[k] > top) {
+                top = count[k];
+                n_top = 1;
+                mode = k;
+            } else if (count[k] == top) {
+                ++n_top;
+            }
+        }
+        if (n_unique == 1 || n_top == 1) return lo + (int64_t)mode;
+        // order statistics n/2 - 1 and n/2 (0-based) from the counts
+        const size_t want_b = n / 2, want_a = n % 2 == 1 ? n / 2 : n / 2 - 1;
+        int64_t a = 0, b = 0;
+        size_t seen = 0;
+        bool have_a = false;
+        for (size_t k = 0; k < count.size(); ++k) {
+            seen += (size_t)count[k];
+            if (!have_a && seen > want_a) {
+                a = lo + (int64_t)k;
+                have_a = true;
+            }
+            if (seen > want_b) {
+                b = lo + (int64_t)k;
+                break;
+            }
+        }
+        return n % 2 == 1 ? b : round_median(a, b);
+    }
     std::sort(v.begin(), v.end());
     size_t top = 0, n_top = 0, n_unique = 0;
     int64_t mode = v[0];
-    for (size_t a = 0; a < v.size();) {
+    for (size_t a = 0; a < n;) {
         size_t b = a;
-        while (b < v.size() && v[b] == v[a]) ++b;
+        while (b < n && v[b] == v[a]) ++b;
         ++n_unique;
         if (b - a > top) {
             top = b - a;
@@ -56,11 +103,40 @@ int64_t consensus(std::vector<int64_t> &v, bool last_is_plus) {
         a = b;
     }
     if (n_unique == 1 || n_top == 1) return mode;
-    const size_t n = v.size();
     if (n % 2 == 1) return v[n / 2];
-    const double med = ((double)v[n / 2 - 1] + (double)v[n / 2]) / 2.0;
-    return (int64_t)(last_is_plus ? ceil(med) : floor(med));
+    return round_median(v[n / 2 - 1], v[n / 2]);
 }
+
+// Number of distinct (read, i, j) triples among the supporting candidates (len(set(tuples)), ibg:443 / :699 / :783).
+struct TripleSet {
+    std::vector<std::array<int64_t, 3>> slot;
+    std::vector<uint8_t> used;
+    size_t distinct(const View &c, const std::vector<int64_t> &sup) {
+        size_t cap = 16;
+        while (cap < sup.size() * 2) cap <<= 1;
+        slot.resize(cap);
+        used.assign(cap, 0);
+        size_t n = 0;
+        for (int64_t i : sup) {
+            const std::array<int64_t, 3> t = {c.at(READ, i), c.at(SI, i), c.at(SJ, i)};
+            uint64_t h = (uint64_t)t[0] * 0x9E3779B97F4A7C15ull;
+            h ^= ((uint64_t)t[1] + 0x7F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+            h ^= ((uint64_t)t[2] + 0x94D049BBull) * 0x94D049BB133111EBull;
+            size_t k = (size_t)(h ^ (h >> 29)) & (cap - 1);
+            for (;;) {
+                if (!used[k]) {
+                    used[k] = 1;
+                    slot[k] = t;
+                    ++n;
+                    break;
+                }
+                if (slot[k] == t) break;
+                k = (k + 1) & (cap - 1);
+            }
+        }
+        return n;
+    }
+};
 }  // namespace
 
 extern "C" int coral_call_breakpoints(int64_t n, const int64_t *const *field_ptr, const int64_t *field_stride,
@@ -125,7 +201,8 @@ extern "C" int coral_call_breakpoints(int64_t n, const int64_t *const *field_ptr
     call_sup_off[0] = 0;
     std::vector<int64_t> rest, next, vals1, vals2, sup;
     std::vector<uint8_t> keep, ok;
-    std::vector<std::array<int64_t, 3>> trip;
+    std::vector<int32_t> count;
+    TripleSet triples;
     for (auto &cluster : clusters) {
         cluster_size[(*n_clusters)++] = (int32_t)cluster.size();
         if ((double)cluster.size() < min_cluster_cutoff) continue;
@@ -157,8 +234,8 @@ extern "C" int coral_call_breakpoints(int64_t n, const int64_t *const *field_ptr
             int64_t bp1 = o1 == 0 ? 0 : 1000000000, bp2 = o2 == 0 ? 0 : 1000000000;
             if (!vals1.empty()) {
                 const int64_t last = rest.back();
-                bp1 = consensus(vals1, c.at(O1, last) == 0);
-                bp2 = consensus(vals2, c.at(O2, last) == 0);
+                bp1 = consensus(vals1, c.at(O1, last) == 0, count);
+                bp2 = consensus(vals2, c.at(O2, last) == 0, count);
             }
             // bp_match of every member against (bp1, bp2)
             sup.clear();
@@ -192,10 +269,7 @@ extern "C" int coral_call_breakpoints(int64_t n, const int64_t *const *field_ptr
                 (match ? sup : next).push_back(i);
             }
             if (sup.empty()) break;                            // no support: nothing to report, nothing left (bu:374-376)
-            trip.clear();
-            for (int64_t i : sup) trip.push_back({c.at(READ, i), c.at(SI, i), c.at(SJ, i)});
-            std::sort(trip.begin(), trip.end());
-            const int64_t n_distinct = (int64_t)(std::unique(trip.begin(), trip.end()) - trip.begin());
+            const int64_t n_distinct = (int64_t)triples.distinct(c, sup);
             if ((sub == 0 && (double)n_distinct >= min_cluster_cutoff) || (double)n_distinct >= accept_floor) {
                 const double k = (double)sup.size();
                 wide_t a1 = 0, a11 = 0, a2 = 0, a22 = 0;

@@ -43,16 +43,21 @@ extern "C" int coral_cluster_first_fit(int64_t n, const int64_t *p1, const int64
         const int64_t x = p1[i], y = p2[i];
         const int64_t cx = floor_div(x, cutoff), cy = floor_div(y, cutoff);
         int32_t best = INT32_MAX;
-        for (int64_t dx = -1; dx <= 1; ++dx)
-            for (int64_t dy = -1; dy <= 1; ++dy) {
-                auto it = grid.find(cell_key(cx + dx, cy + dy));
-                if (it == grid.end()) continue;
-                for (const Cell &c : it->second) {
-                    if (c.cx != cx + dx || c.cy != cy + dy) continue;
-                    for (const Member &m : c.m)
-                        if (m.cluster < best && llabs(x - m.a) < cutoff && llabs(y - m.b) < cutoff) best = m.cluster;
-                }
+        // own cell first: most candidates repeat coordinates of cluster 0, and nothing can beat cluster 0
+        static const int order9[9][2] = {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-1, -1}, {-1, 1}, {1, -1}, {1, 1}};
+        for (int q = 0; q < 9 && best != 0; ++q) {
+            const int64_t dx = order9[q][0], dy = order9[q][1];
+            auto it = grid.find(cell_key(cx + dx, cy + dy));
+            if (it == grid.end()) continue;
+            for (const Cell &c : it->second) {
+                if (c.cx != cx + dx || c.cy != cy + dy) continue;
+                for (const Member &m : c.m)
+                    if (m.cluster < best && llabs(x - m.a) < cutoff && llabs(y - m.b) < cutoff) {
+                        best = m.cluster;
+                        if (best == 0) break;
+                    }
             }
+        }
         if (best == INT32_MAX) best = ncl++;
         cluster_of[i] = best;
         std::vector<Cell> &bucket = grid[cell_key(cx, cy)];
