@@ -196,7 +196,16 @@ __device__ __forceinline__ int wave_sum_dpp(int x) {
 }
 
 // BATCH = chunks (KiB) a wave loads back to back: BATCH KiB per wave in flight while the previous batch is processed
-template <int BATCH, bool LIGHT = false>
+// FILTER = true (variant 7): a chunk first passes a cheap, conservative "can this chunk hold a large gap at all?" test and
+// only the chunks that fail it run the exact gap search (max-scan over the wave + per-op distance tests).  A gap is the
+// sum of the reference-advancing NON-aligned ops (D, N) between two consecutive aligned ops.  With G(l) = that sum over
+// the four ops of lane l, a lane is flagged when it holds real ops but no aligned op, or when G(l) > min_gap / 2.  If no
+// lane of a chunk is flagged and the last lane of the previous chunk of the record was not flagged either, then two
+// consecutive aligned ops are at most one lane apart (a lane in between would have no aligned op), so every gap that ends
+// in this chunk is <= G(l) + G(l + 1) <= min_gap: nothing to report, and the running "end of the last aligned block" is
+// simply the one of the highest lane holding an aligned op.  Exact for every input; CIGARs of real reads trip the filter
+// only around actual large deletions and at the (padded) end of a record.
+template <int BATCH, bool LIGHT = false, bool FILTER = false>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
     long long n_rec, const int32_t *__restrict__ pos, const int32_t *__restrict__ flagmq,
     const int32_t *__restrict__ n_cigar, const int64_t *__restrict__ cigar_off,
@@ -272,6 +281,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
     f_step();
 
     int carry_ref = 0, carry_end = 0, msum = 0, qsum = 0, first = 0;
+    bool tail_flagged = false;                  // FILTER: last lane of the record's previous chunk was flagged
+    const int half_gap = min_gap >> 1;
     while (pr < n_rec) {
         // Touch the current batch: the compiler places its wait for these registers HERE, i.e. before the next
         // batch is issued, so the next 4 KiB stay in flight for the whole of this batch's arithmetic.
@@ -291,22 +302,60 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
             // ---- branch-free decode of the lane's four ops
             int len[4], adv[4], aend[4], ref[4];
             bool aln[4];
-            int tot = 0;
+            int fal[4];                          // FILTER: 0 / -1 per op, "is an aligned block"
+            int tot = 0, asum = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t w = b0[k];
-                const uint32_t f = (uint32_t)(OPCLASS >> ((w << 2) & 60u));
                 len[k] = (int)(w >> 4);
-                adv[k] = len[k] & -(int)(f & 1u);
-                const int alen = len[k] & -(int)((f >> 1) & 1u);
-                aln[k] = (f >> 1) & 1u;
-                aend[k] = alen;
-                msum += alen;
-                qsum += len[k] & -(int)((f >> 2) & 1u);
+                if (FILTER) {
+                    // v_bfe_i32 takes its bit offset from the low 5 bits of the operand: op code + 16 * (length & 1);
+                    // the class masks are replicated into both halves, so the op word itself is the offset.
+                    const int fr_ = __builtin_amdgcn_sbfe((int)(MASK_REF * 0x10001u), w, 1u);
+                    const int fa_ = __builtin_amdgcn_sbfe((int)(MASK_ALN * 0x10001u), w, 1u);
+                    const int fq_ = __builtin_amdgcn_sbfe((int)(MASK_QRY * 0x10001u), w, 1u);
+                    adv[k] = len[k] & fr_;
+                    aend[k] = len[k] & fa_;
+                    fal[k] = fa_;
+                    aln[k] = fa_ != 0;
+                    qsum += len[k] & fq_;
+                } else {
+                    const uint32_t f = (uint32_t)(OPCLASS >> ((w << 2) & 60u));
+                    adv[k] = len[k] & -(int)(f & 1u);
+                    aend[k] = len[k] & -(int)((f >> 1) & 1u);
+                    aln[k] = (f >> 1) & 1u;
+                    qsum += len[k] & -(int)((f >> 2) & 1u);
+                }
+                asum += aend[k];
                 tot += adv[k];
             }
+            msum += asum;
             const int incl = wave_incl_scan_add_dpp(tot);
             ref[0] = carry_ref + incl - tot;
+            bool exact = true;
+            if (FILTER) {
+                const int m3 = fal[3], m2 = m3 | fal[2], m1 = m2 | fal[1], m0 = m1 | fal[0];
+                const bool lane_flag = (m0 == 0 && b0[0] != OP_PAD_QUAD) || (tot - asum > half_gap);
+                const unsigned long long flagged = __ballot(lane_flag);
+                exact = flagged != 0ull || tail_flagged;
+                tail_flagged = (flagged >> 63) != 0ull;
+                if (!exact) {
+                    // end of the last aligned block of every lane, relative to the lane's first op
+                    const int off_end = adv[0] + (adv[1] & m1) + (adv[2] & m2) + (adv[3] & m3);
+                    const unsigned long long has = __ballot(m0 != 0);   // 0 only for a record without any op (all padding)
+                    if (has != 0ull) {
+                        if (carry_end == 0) {        // (wave-uniform) the record's first block starts in this chunk
+                            int lf = ref[0] + adv[0] + adv[1] + adv[2];
+                            lf = aln[2] ? ref[0] + adv[0] + adv[1] : lf;
+                            lf = aln[1] ? ref[0] + adv[0] : lf;
+                            lf = aln[0] ? ref[0] : lf;
+                            first = __builtin_amdgcn_readlane(lf, (int)__builtin_ctzll(has));
+                        }
+                        carry_end = __builtin_amdgcn_readlane(ref[0] + off_end, 63 - (int)__builtin_clzll(has));
+                    }
+                }
+            }
+            if (exact) {
             ref[1] = ref[0] + adv[0];
             ref[2] = ref[1] + adv[1];
             ref[3] = ref[2] + adv[2];
@@ -358,8 +407,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
                     }
                 }
             }
-            carry_ref += __builtin_amdgcn_readlane(incl, 63);
             carry_end = max(carry_end, __builtin_amdgcn_readlane(mx, 63));
+            }
+            carry_ref += __builtin_amdgcn_readlane(incl, 63);
         }
 
         if (pc + BATCH * WAVE >= pnq) {          // last batch of this record: write its summary, move on
@@ -372,6 +422,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
                 blk_last[pr] = (carry_end > 0) ? p0 + carry_end : -1;
             }
             carry_ref = 0; carry_end = 0; msum = 0; qsum = 0; first = 0;
+            tail_flagged = false;
             pr += nwaves;
             p_meta();
         } else {
@@ -571,6 +622,109 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_flat(
     while (r < rb) finish_record();      // records without any op at the end of the range
 }
 
+// ---------------------------------------------------------------------------------------------
+// K1 (variant 8, "packed")  like variant 3, but the fetch and process cursors advance CHUNK BY CHUNK: the BATCH loads a
+// wave has in flight are the next BATCH chunks of its record sequence, whichever records they belong to.  Variants 2-4
+// never let a batch span two records, so a record of L KiB occupies ceil(L / BATCH) whole batches and the load slots
+// of the unused tail stay empty (about a third of them at 8 KiB batches and 7.4 KiB mean records); here only the last,
+// partial chunk of a record is padding.  A chunk still belongs to one record, so the arithmetic (scan_chunk) is
+// unchanged; the end-of-record summary moves inside the chunk loop.
+// ---------------------------------------------------------------------------------------------
+template <int BATCH>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_packed(
+    long long n_rec, const int32_t *__restrict__ pos, const int32_t *__restrict__ flagmq,
+    const int32_t *__restrict__ n_cigar, const int64_t *__restrict__ cigar_off,
+    const uint32_t *__restrict__ cigar, int min_gap, int min_mapq, int32_t *__restrict__ mbases,
+    int32_t *__restrict__ qinfer, int32_t *__restrict__ blk_first, int32_t *__restrict__ blk_last,
+    int32_t *__restrict__ gaps, uint32_t *__restrict__ gap_count, uint32_t gap_cap) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (SCAN_BLOCK / WAVE) + (threadIdx.x >> 6)));
+    const long long nwaves = (long long)gridDim.x * (SCAN_BLOCK / WAVE);
+    const cquad_t pad = {OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD};
+    const long long last_rec = n_rec - 1;      // n_rec >= 1 (checked by the launcher)
+
+    // fetch cursor (record, chunk): metadata is wave-uniform, loaded with scalar loads one record ahead of its use
+    long long fr = wave;
+    int fc = 0, fnq = 0;
+    const cquad_t *__restrict__ fq = reinterpret_cast<const cquad_t *>(cigar);
+    int f_nn = 0;
+    long long f_noff = 0;
+    auto f_request = [&](long long r) {
+        const long long rr = r < n_rec ? r : last_rec;
+        f_nn = n_cigar[rr];
+        f_noff = cigar_off[rr];
+    };
+    auto f_meta = [&]() {
+        fc = 0;
+        fnq = fr < n_rec ? (f_nn + 3) >> 2 : 0;
+        fq = reinterpret_cast<const cquad_t *>(cigar + f_noff);
+        f_request(fr + nwaves);
+    };
+    auto f_chunk = [&](cquad_t &dst) {          // load the chunk under the cursor, then step (every record has >= 1 chunk)
+        dst = pad;
+        if (fc + lane < fnq) dst = fq[fc + lane];
+        fc += WAVE;
+        if (fc >= fnq) {
+            fr += nwaves;
+            f_meta();
+        }
+    };
+    // process cursor
+    long long pr = wave;
+    int pc = 0, pnq = 0, p0 = 0;
+    bool gaps_on = false;
+    int p_nn = 0, p_npos = 0, p_nfm = 0;
+    auto p_request = [&](long long r) {
+        const long long rr = r < n_rec ? r : last_rec;
+        p_nn = n_cigar[rr];
+        p_npos = pos[rr];
+        p_nfm = flagmq[rr];
+    };
+    auto p_meta = [&]() {
+        pc = 0;
+        pnq = (p_nn + 3) >> 2;
+        p0 = p_npos;
+        gaps_on = ((p_nfm >> 16) & 0xff) >= min_mapq;
+        p_request(pr + nwaves);
+    };
+    f_request(fr);
+    p_request(pr);
+    f_meta();
+    p_meta();
+    cquad_t cur[BATCH], nxt[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) f_chunk(cur[j]);
+
+    RecState st = {0, 0, 0, 0, 0};
+    while (pr < n_rec) {
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) asm volatile("" : "+v"(cur[j]));     // wait for this batch before issuing the next
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) f_chunk(nxt[j]);
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            if (pr >= n_rec) break;                     // wave-uniform: this wave's records are done
+            scan_chunk(cur[j], lane, st, gaps_on, min_gap, (int)pr, pc, p0, gaps, gap_count, gap_cap);
+            pc += WAVE;
+            if (pc >= pnq) {                            // last chunk of the record: write its summary, move on
+                const int ms = wave_sum_dpp(st.msum);
+                const int qs = wave_sum_dpp(st.qsum);
+                if (lane == 0) {
+                    mbases[pr] = ms;
+                    qinfer[pr] = qs;
+                    blk_first[pr] = (st.carry_end > 0) ? p0 + st.first : -1;
+                    blk_last[pr] = (st.carry_end > 0) ? p0 + st.carry_end : -1;
+                }
+                st = {0, 0, 0, 0, 0};
+                pr += nwaves;
+                p_meta();
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) cur[j] = nxt[j];
+    }
+}
+
 // Streaming-read probe: what a plain grid-stride 16-byte-per-lane read of the same CIGAR bytes achieves
 // (upper bound for any kernel that must touch every op once).
 __global__ __launch_bounds__(256) void k_stream_probe(const cquad_t *__restrict__ q, long long n_quads, uint32_t *__restrict__ out) {
@@ -627,7 +781,7 @@ extern "C" int coral_time_stream_read(const uint32_t *cigar, long long n_words, 
 
 static int g_scan_variant = 3;   // 8 KiB per wave in flight: best on average over the boxes measured (profiles/r01_scan_variants.md)
 extern "C" int coral_set_scan_variant(int v) {
-    if (v < 1 || v > 6) return CORAL_ERR_ARG;
+    if (v < 1 || v > 9) return CORAL_ERR_ARG;
     g_scan_variant = v;
     return CORAL_OK;
 }
@@ -672,6 +826,18 @@ extern "C" int coral_cigar_scan(const coral_records_t *rec, int32_t min_gap, int
         LAUNCH_V2(2);
     else if (g_scan_variant == 6)
         hipLaunchKernelGGL(k_cigar_scan_flat<4>, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
+                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
+                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
+    else if (g_scan_variant == 8)
+        hipLaunchKernelGGL(k_cigar_scan_packed<8>, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
+                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
+                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
+    else if (g_scan_variant == 9)
+        hipLaunchKernelGGL(k_cigar_scan_packed<4>, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
+                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
+                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
+    else if (g_scan_variant == 7)
+        hipLaunchKernelGGL((k_cigar_scan_v2<8, false, true>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
                            (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
                            (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
     else if (g_scan_variant == 5)

@@ -315,9 +315,24 @@ class bam_to_breakpoint_nanopore():
         return np.where(hits.any(1), ix[np.argmax(hits, 1)], -1)
 
     # ---- A3 ----------------------------------------------------------------------------------
+    def launch_record_kernels(self):
+        """Issue the two passes that depend on the records alone — the SA table (K3) and the fused CIGAR scan — back to back,
+        before any host logic runs: the scan then starts on a GPU that is already clocked up instead of after the host-side
+        gap between two steps.  What fetch() would raise is kept and raised there."""
+        try:
+            self._chim_early = build_chimeric_table(self.rec)
+        except Exception as exc:                      # noqa: BLE001 — re-raised by fetch(), where the reference raises
+            self._chim_early = exc
+        self.scan()
+
     def fetch(self):
         """Collect chimeric alignments of every read from the SA tags (ibg:139-174)."""
-        T = build_chimeric_table(self.rec)
+        T = getattr(self, "_chim_early", None)
+        self._chim_early = None
+        if isinstance(T, Exception):
+            raise T
+        if T is None:
+            T = build_chimeric_table(self.rec)
         self._chim = T
         if T.n_mapq60_plain == 0:
             raise ZeroDivisionError("float division by zero")                # ibg:159
@@ -1273,6 +1288,8 @@ def _build_graph_from_records(records, seedfile, cn_seg, output_prefix, min_bp_s
     PHASE_SECONDS.clear()
     b2bn = bam_to_breakpoint_nanopore(None, seedfile, records=records)
     b2bn.min_bp_cov_factor = min_bp_support
+    if os.environ.get("CORAL_NO_EARLY_LAUNCH") != "1":
+        b2bn.launch_record_kernels()
     lap("open", "Opened LR bam files.")
     b2bn.read_cns(cn_seg)
     lap("read_cns", "Completed parsing CN segment files.")

@@ -26,14 +26,51 @@ def _odd_records():
     return synth.records_from_alignments(alns)
 
 
+def _adversarial_records(seed=5, n=160):
+    """Random CIGARs built to sit on the gap filter's edges: D/N runs whose sums hover around min_gap / 2 and min_gap,
+    runs of non-aligned ops longer than one and two lanes (4 and 8 ops), placed across quad, chunk (256 ops) and batch
+    (2048 ops) boundaries, records that end in D/N/S, and records without any aligned op."""
+    M, I, D, N, S, H, P, EQ, X = range(9)
+    rng = np.random.default_rng(seed)
+    alns, pos = [], 1000
+    for r in range(n):
+        ops = []
+        target = int(rng.choice([3, 9, 250, 262, 600, 2040, 2050, 2300, 4100]))
+        if rng.random() < 0.3:
+            ops.append((S, int(rng.integers(1, 50))))
+        while len(ops) < target:
+            kind = rng.random()
+            if kind < 0.55:
+                ops.append((int(rng.choice([M, EQ, X])), int(rng.integers(1, 40))))
+            elif kind < 0.75:
+                ops.append((int(rng.choice([D, N])), int(rng.choice([1, 2, 149, 150, 151, 299, 300, 301, 302, 599, 600, 601, 1200]))))
+            elif kind < 0.9:
+                ops.append((int(rng.choice([I, P])), int(rng.integers(1, 6))))
+            else:                                   # a run of non-aligned ops, up to three lanes long
+                for _ in range(int(rng.integers(2, 13))):
+                    ops.append((int(rng.choice([D, N, I, P])), int(rng.choice([1, 100, 150, 200, 299, 300, 301, 602]))))
+        tail = rng.random()
+        if tail < 0.3:
+            ops.append((int(rng.choice([S, H])), int(rng.integers(1, 30))))
+        elif tail < 0.45:
+            ops.append((D, int(rng.choice([5, 700]))))
+        if r % 23 == 7:
+            ops = [(S, 10), (I, 4), (D, 700), (I, 2)]      # no aligned block at all
+        # merge nothing: adjacent equal ops are legal in BAM and must not be merged by us
+        alns.append(dict(tid=0, pos=pos, cigar=ops, name="adv%d" % r, mapq=int(rng.choice([60, 60, 60, 19]))))
+        pos += int(rng.integers(1, 50))
+    return synth.records_from_alignments(alns)
+
+
 def _cases():
     yield "odd", _odd_records()
+    yield "adversarial", _adversarial_records()
     for name in ("tiny", "small", "ultra"):
         yield name, synth.generate(synth.named_config(name), "cpu")
     yield "cfg1_8k", synth.generate(synth.scaled_config("cfg1", 8000), "cpu")
 
 
-@pytest.fixture(scope="module", params=["odd", "tiny", "small", "ultra", "cfg1_8k"])
+@pytest.fixture(scope="module", params=["odd", "adversarial", "tiny", "small", "ultra", "cfg1_8k"])
 def case(request):
     from coral_amd.records import DeviceRecords
     from oracle.hostrecords import HostRecords
@@ -41,9 +78,10 @@ def case(request):
     return request.param, rec, HostRecords(rec), DeviceRecords(rec, "cuda:0")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9])
 def test_cigar_scan(case, variant):
-    """Every variant of the scan kernel (first version, batched per-record 2/4/8 KiB, flat contiguous ranges)."""
+    """Every variant of the scan kernel (first version, batched per-record 2/4/8 KiB, flat contiguous ranges, and the
+    8 KiB one with the conservative per-chunk gap filter)."""
     from coral_amd import kernels, _lib
     name, rec, host, dr = case
     assert _lib.lib().coral_set_scan_variant(variant) == 0
@@ -70,6 +108,31 @@ def test_cigar_scan(case, variant):
     assert got == gaps, name
     if name == "odd":
         assert len(gaps) == 5     # a, b(N), e, i x2
+
+
+@pytest.mark.parametrize("min_gap", [0, 1, 3, 299, 300, 301, 601, 1199, 5000])
+def test_cigar_scan_gap_filter_thresholds(min_gap):
+    """The filtered variant against the oracle's blocks for thresholds around the D/N lengths of the adversarial set
+    (odd and even: the filter flags a lane at G > min_gap // 2)."""
+    from coral_amd import kernels, _lib
+    from coral_amd.records import DeviceRecords
+    from oracle.hostrecords import HostRecords
+    rec = _adversarial_records(seed=17 + min_gap, n=120)
+    host, dr = HostRecords(rec), DeviceRecords(rec, "cuda:0")
+    assert _lib.lib().coral_set_scan_variant(7) == 0, "variant 7 missing"
+    try:
+        res = kernels.cigar_scan(dr, min_gap, 20)
+    finally:
+        _lib.lib().coral_set_scan_variant(3)
+    want = []
+    for i in range(host.n):
+        bl = host.blocks(i)
+        if host.mapq[i] >= 20:
+            want += [(i, bl[k][1], bl[k + 1][0]) for k in range(len(bl) - 1) if bl[k + 1][0] - bl[k][1] > min_gap]
+        assert int(res.blk_first[i]) == (bl[0][0] if bl else -1) and int(res.blk_last[i]) == (bl[-1][1] if bl else -1), i
+        assert int(res.mbases[i]) == sum(e - s for s, e in bl)
+    assert [(int(g[0]), int(g[2]), int(g[3])) for g in res.gaps] == want
+    assert len(want) > 50 or min_gap >= 1199
 
 
 def _random_segments(host, rng, n):

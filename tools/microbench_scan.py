@@ -19,6 +19,11 @@ L0.coral_set_scan_variant(1); r1 = kernels.cigar_scan(dr)
 L0.coral_set_scan_variant(2); res = kernels.cigar_scan(dr)
 import numpy as np
 assert torch.equal(r1.mbases, res.mbases) and torch.equal(r1.qinfer, res.qinfer) and torch.equal(r1.blk_first, res.blk_first) and torch.equal(r1.blk_last, res.blk_last) and np.array_equal(r1.gaps, res.gaps), "variants disagree"
+assert L0.coral_set_scan_variant(7) == 0; r7 = kernels.cigar_scan(dr)
+assert torch.equal(r7.mbases, res.mbases) and torch.equal(r7.qinfer, res.qinfer) and torch.equal(r7.blk_first, res.blk_first) and torch.equal(r7.blk_last, res.blk_last) and np.array_equal(r7.gaps, res.gaps), "filtered variant disagrees"
+for v in (8, 9):
+    assert L0.coral_set_scan_variant(v) == 0; r8 = kernels.cigar_scan(dr)
+    assert torch.equal(r8.mbases, res.mbases) and torch.equal(r8.qinfer, res.qinfer) and torch.equal(r8.blk_first, res.blk_first) and torch.equal(r8.blk_last, res.blk_last) and np.array_equal(r8.gaps, res.gaps), "packed variant disagrees"
 L0.coral_set_scan_variant(6); r6 = kernels.cigar_scan(dr)
 assert torch.equal(r6.mbases, res.mbases) and torch.equal(r6.qinfer, res.qinfer) and torch.equal(r6.blk_first, res.blk_first) and torch.equal(r6.blk_last, res.blk_last) and np.array_equal(r6.gaps, res.gaps), "flat variant disagrees"
 print("gaps", res.gaps.shape, "variants agree (1, 2, 6)")
@@ -27,11 +32,12 @@ rs = dr.c_struct()
 mb = torch.empty(dr.n, dtype=torch.int32, device="cuda"); qi = torch.empty_like(mb); b0 = torch.empty_like(mb); b1 = torch.empty_like(mb)
 gaps = torch.empty((1 << 20, 4), dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
 ms = C.c_float(0)
-for it in range(12):
-    L.coral_set_scan_variant(1 + it % 6)
+VARIANTS = [3, 5, 7, 8, 9]
+for it in range(3 * len(VARIANTS)):
+    L.coral_set_scan_variant(VARIANTS[it % len(VARIANTS)])
     _lib.check(L.coral_time_cigar_scan(C.byref(rs), 600, 20, mb.data_ptr(), qi.data_ptr(), b0.data_ptr(), b1.data_ptr(), gaps.data_ptr(), cnt.data_ptr(), 1 << 20, 10, C.byref(ms), dr.stream()), "time")
     B = dr.algorithmic_bytes()
-    print("variant %d" % (1 + it % 6), "scan %.3f ms/launch  alg bytes %.3f GB  -> %.1f GB/s (%.1f%% of 8 TB/s)" % (ms.value, B / 1e9, B / ms.value / 1e6, B / ms.value / 1e6 / 80), flush=True)
+    print("variant %d" % VARIANTS[it % len(VARIANTS)], "scan %.3f ms/launch  alg bytes %.3f GB  -> %.1f GB/s (%.1f%% of 8 TB/s)" % (ms.value, B / 1e9, B / ms.value / 1e6, B / ms.value / 1e6 / 80), flush=True)
 
 scr = torch.zeros(4, dtype=torch.int32, device="cuda")
 for it in range(4):
@@ -42,7 +48,7 @@ for it in range(4):
     print("plain streaming read %.3f ms  -> %.1f GB/s" % (ms.value, dr.cigar.numel() * 4 / ms.value / 1e6), flush=True)
 
 import time as _t
-L.coral_set_scan_variant(3)
+L.coral_set_scan_variant(int(sys.argv[3]) if len(sys.argv) > 3 else 3)
 for idle in (0.0, 0.2, 1.0, 1.0):
     _t.sleep(idle)
     _lib.check(L.coral_time_cigar_scan(C.byref(rs), 600, 20, mb.data_ptr(), qi.data_ptr(), b0.data_ptr(), b1.data_ptr(), gaps.data_ptr(), cnt.data_ptr(), 1 << 20, 1, C.byref(ms), dr.stream()), "time")
