@@ -20,6 +20,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+# name of the kernel behind coral_cigar_scan per coral_set_scan_variant value (0 = library default = 7)
+SCAN_KERNEL_NAME = {0: "k_cigar_scan_v2<8, false, true>", 7: "k_cigar_scan_v2<8, false, true>", 3: "k_cigar_scan_v2<8, false, false>",
+                    13: "k_cigar_scan_ring_asm<8, true>", 10: "k_cigar_scan_ring<8, true>", 8: "k_cigar_scan_packed<8>"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -30,6 +35,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=50000, help="reads in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of N > 1)")
     ap.add_argument("--shared-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--scan-variant", type=int, default=0, help="A/B only: coral_set_scan_variant (0 = library default)")
     a = ap.parse_args()
 
     import torch
@@ -54,6 +60,9 @@ def main():
     from coral_amd.records import DeviceRecords
     from coral_amd import sharding
 
+    if a.scan_variant:
+        from coral_amd import _lib
+        _lib.check(_lib.lib().coral_set_scan_variant(a.scan_variant), "coral_set_scan_variant")
     cfg = synth.named_config(a.config)
     if a.reads:
         cfg.n_reads = a.reads
@@ -112,8 +121,8 @@ def main():
                        "discordant_edges": sum(len(g.discordant_edges) for g in b.lr_graph),
                        "generate_s": round(gen_s, 2), "parallelism": "records sharded over %d GPU(s)" % world,
                        "phase_ms_last_step": {k: round(v * 1e3, 1) for k, v in ibg.PHASE_SECONDS.items()}},
-            "roofline": {"bound": "hbm", "kernel": "k_cigar_scan_v2<8>", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": pmc_traffic(cfg, world), "launch_ms": scan_ms_avg,
+            "roofline": {"bound": "hbm", "kernel": SCAN_KERNEL_NAME.get(a.scan_variant, "variant %d" % a.scan_variant), "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": pmc_traffic(cfg, world, SCAN_KERNEL_NAME.get(a.scan_variant)), "launch_ms": scan_ms_avg,
                          "algorithmic_bytes_per_launch": int(alg_bytes_local)},
         }
         if a.cpu_sample and world == 1:
@@ -125,13 +134,13 @@ def main():
     shutil.rmtree(work, ignore_errors=True)
 
 
-def pmc_traffic(cfg, world):
+def pmc_traffic(cfg, world, kernel):
     """HBM bytes per scan launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json) when they
     were taken on exactly this workload on one GPU; counters cannot be collected from inside this process -> else None."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fp:
             p = json.load(fp)
-        if world == 1 and p["workload"] == cfg.name and p["n_reads"] == cfg.n_reads:
+        if world == 1 and p["workload"] == cfg.name and p["n_reads"] == cfg.n_reads and p["scan_kernel"] == kernel:
             return p["kernels"][p["scan_kernel"]]["hbm_bytes"]
     except (OSError, KeyError, ValueError):
         pass

@@ -301,8 +301,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
             const cquad_t b0 = cur[j];
             // ---- branch-free decode of the lane's four ops
             int len[4], adv[4], aend[4], ref[4];
-            bool aln[4];
-            int fal[4];                          // FILTER: 0 / -1 per op, "is an aligned block"
+            int fal[4];                          // 0 / -1 per op, "is an aligned block"
             int tot = 0, asum = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -317,13 +316,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
                     adv[k] = len[k] & fr_;
                     aend[k] = len[k] & fa_;
                     fal[k] = fa_;
-                    aln[k] = fa_ != 0;
                     qsum += len[k] & fq_;
                 } else {
                     const uint32_t f = (uint32_t)(OPCLASS >> ((w << 2) & 60u));
                     adv[k] = len[k] & -(int)(f & 1u);
                     aend[k] = len[k] & -(int)((f >> 1) & 1u);
-                    aln[k] = (f >> 1) & 1u;
+                    fal[k] = -(int)((f >> 1) & 1u);
                     qsum += len[k] & -(int)((f >> 2) & 1u);
                 }
                 asum += aend[k];
@@ -335,27 +333,26 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
             bool exact = true;
             if (FILTER) {
                 const int m3 = fal[3], m2 = m3 | fal[2], m1 = m2 | fal[1], m0 = m1 | fal[0];
-                const bool lane_flag = (m0 == 0 && b0[0] != OP_PAD_QUAD) || (tot - asum > half_gap);
-                const unsigned long long flagged = __ballot(lane_flag);
+                const unsigned long long flagged = (__ballot(m0 == 0) & __ballot(b0[0] != OP_PAD_QUAD)) | __ballot(tot - asum > half_gap);
                 exact = flagged != 0ull || tail_flagged;
                 tail_flagged = (flagged >> 63) != 0ull;
                 if (!exact) {
-                    // end of the last aligned block of every lane, relative to the lane's first op
-                    const int off_end = adv[0] + (adv[1] & m1) + (adv[2] & m2) + (adv[3] & m3);
                     const unsigned long long has = __ballot(m0 != 0);   // 0 only for a record without any op (all padding)
                     if (has != 0ull) {
-                        if (carry_end == 0) {        // (wave-uniform) the record's first block starts in this chunk
-                            int lf = ref[0] + adv[0] + adv[1] + adv[2];
-                            lf = aln[2] ? ref[0] + adv[0] + adv[1] : lf;
-                            lf = aln[1] ? ref[0] + adv[0] : lf;
-                            lf = aln[0] ? ref[0] : lf;
+                        if (carry_end == 0) {        // (wave-uniform) the record's first block starts in this chunk:
+                            // reference-advancing ops in front of the lane's first aligned op (masks only, no selects)
+                            const int n0 = ~fal[0], n1 = n0 & ~fal[1], n2 = n1 & ~fal[2];
+                            const int lf = ref[0] + (adv[0] & n0) + (adv[1] & n1) + (adv[2] & n2);
                             first = __builtin_amdgcn_readlane(lf, (int)__builtin_ctzll(has));
                         }
+                        // end of the last aligned block of the lane, relative to the lane's first op
+                        const int off_end = adv[0] + (adv[1] & m1) + (adv[2] & m2) + (adv[3] & m3);
                         carry_end = __builtin_amdgcn_readlane(ref[0] + off_end, 63 - (int)__builtin_clzll(has));
                     }
                 }
             }
             if (exact) {
+            const bool aln[4] = {fal[0] != 0, fal[1] != 0, fal[2] != 0, fal[3] != 0};
             ref[1] = ref[0] + adv[0];
             ref[2] = ref[1] + adv[1];
             ref[3] = ref[2] + adv[2];
@@ -725,6 +722,352 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_packed(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K1 (variant 10, "ring")  the production scan kernel.
+//   * chunk-granular fetch / process cursors as in the packed variant: the BATCH loads a wave keeps in flight are the
+//     next BATCH chunks of its record sequence, whatever records they belong to;
+//   * the register ring is refilled IN PLACE: chunk slot j is reloaded right after its arithmetic, so there is no second
+//     buffer (half the data registers of variants 2-8 -> more waves per SIMD) and no register copies;
+//   * a full chunk is loaded with an SGPR base + the constant lane offset and no exec masking (zero vector instructions per
+//     load); only a record's last, partial chunk takes the masked path with padding;
+//   * the arithmetic first applies the conservative gap filter of variant 7 (see k_cigar_scan_v2) and runs the exact
+//     max-scan / distance tests only on the chunks that fail it.
+// The kernel is vector-ALU bound when launched on its own (profiles/r01_scan_variants.md): every instruction removed
+// from the per-chunk path shows up in the launch time.
+// ---------------------------------------------------------------------------------------------
+struct RingState {
+    int carry_ref, carry_end, msum, qsum, first;
+    bool tail_flagged;
+};
+
+template <bool FILTER>
+__device__ __forceinline__ void ring_chunk(const cquad_t b0, const int lane, RingState &st, const bool gaps_on, const int min_gap,
+                                           const int half_gap, const int rec, const int quad_in_rec, const int p0,
+                                           int32_t *__restrict__ gaps, uint32_t *__restrict__ gap_count, const uint32_t gap_cap) {
+    int len[4], adv[4], fal[4];
+    int tot = 0, asum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t w = b0[k];
+        len[k] = (int)(w >> 4);
+        // v_bfe_i32 takes its bit offset from the low 5 bits of the operand (op code + 16 * (length & 1)); the class masks are
+        // replicated into both halves, so the op word itself serves as the offset: 0 / -1 per class in one instruction.
+        const int fr_ = __builtin_amdgcn_sbfe((int)(MASK_REF * 0x10001u), w, 1u);
+        const int fa_ = __builtin_amdgcn_sbfe((int)(MASK_ALN * 0x10001u), w, 1u);
+        const int fq_ = __builtin_amdgcn_sbfe((int)(MASK_QRY * 0x10001u), w, 1u);
+        adv[k] = len[k] & fr_;
+        fal[k] = fa_;
+        asum += len[k] & fa_;
+        st.qsum += len[k] & fq_;
+        tot += adv[k];
+    }
+    st.msum += asum;
+    const int incl = wave_incl_scan_add_dpp(tot);
+    const int ref0 = st.carry_ref + incl - tot;
+    const int m3 = fal[3], m2 = m3 | fal[2], m1 = m2 | fal[1], m0 = m1 | fal[0];
+    bool exact = true;
+    if (FILTER) {
+        const unsigned long long flagged = (__ballot(m0 == 0) & __ballot(b0[0] != OP_PAD_QUAD)) | __ballot(tot - asum > half_gap);
+        exact = flagged != 0ull || st.tail_flagged;
+        st.tail_flagged = (flagged >> 63) != 0ull;
+        if (!exact) {
+            const unsigned long long has = __ballot(m0 != 0);       // 0 only for a record without any op (all padding)
+            if (has != 0ull) {
+                if (st.carry_end == 0) {     // (wave-uniform) the record's first block starts in this chunk
+                    const int n0 = ~fal[0], n1 = n0 & ~fal[1], n2 = n1 & ~fal[2];
+                    const int lf = ref0 + (adv[0] & n0) + (adv[1] & n1) + (adv[2] & n2);
+                    st.first = __builtin_amdgcn_readlane(lf, (int)__builtin_ctzll(has));
+                }
+                const int off_end = adv[0] + (adv[1] & m1) + (adv[2] & m2) + (adv[3] & m3);
+                st.carry_end = __builtin_amdgcn_readlane(ref0 + off_end, 63 - (int)__builtin_clzll(has));
+            }
+        }
+    }
+    if (exact) {
+        const bool aln[4] = {fal[0] != 0, fal[1] != 0, fal[2] != 0, fal[3] != 0};
+        int ref[4];
+        ref[0] = ref0;
+        ref[1] = ref[0] + adv[0];
+        ref[2] = ref[1] + adv[1];
+        ref[3] = ref[2] + adv[2];
+        int run[4];                          // running "end of the last aligned block" inside the lane (0 = none yet)
+        run[0] = aln[0] ? ref[0] + len[0] : 0;
+        run[1] = aln[1] ? ref[1] + len[1] : run[0];
+        run[2] = aln[2] ? ref[2] + len[2] : run[1];
+        run[3] = aln[3] ? ref[3] + len[3] : run[2];
+        int mx = run[3];                     // previous block end seen by a lane = max over the earlier lanes, else the carry
+        mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x111, 0xf, 0xf, true));
+        mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x112, 0xf, 0xf, true));
+        mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x114, 0xf, 0xf, true));
+        mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x118, 0xf, 0xf, true));
+        mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x142, 0xa, 0xf, true));
+        mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x143, 0xc, 0xf, true));
+        const int shifted = __builtin_amdgcn_update_dpp(st.carry_end, mx, 0x138, 0xf, 0xf, false);   // wave_shr:1
+        const int prev_in = max(shifted, st.carry_end);
+        if (st.carry_end == 0) {
+            const unsigned long long has = __ballot(run[3] != 0);
+            if (has != 0ull) {
+                int lf = ref[3];
+                lf = aln[2] ? ref[2] : lf;
+                lf = aln[1] ? ref[1] : lf;
+                lf = aln[0] ? ref[0] : lf;
+                st.first = __builtin_amdgcn_readlane(lf, (int)__builtin_ctzll(has));
+            }
+        }
+        const int none = 0x3fffffff;
+        const int pin = prev_in == 0 ? none : prev_in;
+        const int pv1 = run[0] ? run[0] : pin, pv2 = run[1] ? run[1] : pin, pv3 = run[2] ? run[2] : pin;
+        const bool h0 = aln[0] && (ref[0] - pin > min_gap);
+        const bool h1 = aln[1] && (ref[1] - pv1 > min_gap);
+        const bool h2 = aln[2] && (ref[2] - pv2 > min_gap);
+        const bool h3 = aln[3] && (ref[3] - pv3 > min_gap);
+        if (gaps_on && __ballot(h0 | h1 | h2 | h3) != 0ull) {
+            const int pv[4] = {pin, pv1, pv2, pv3};
+            const bool hit[4] = {h0, h1, h2, h3};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (hit[k]) {
+                    const uint32_t slot = atomicAdd(gap_count, 1u);
+                    if (slot < gap_cap) {
+                        int4 row = make_int4(rec, (quad_in_rec + lane) * 4 + k, p0 + pv[k], p0 + ref[k]);
+                        reinterpret_cast<int4 *>(gaps)[slot] = row;
+                    }
+                }
+            }
+        }
+        st.carry_end = max(st.carry_end, __builtin_amdgcn_readlane(mx, 63));
+    }
+    st.carry_ref += __builtin_amdgcn_readlane(incl, 63);
+}
+
+template <int BATCH, bool FILTER>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_ring(
+    long long n_rec, const int32_t *__restrict__ pos, const int32_t *__restrict__ flagmq,
+    const int32_t *__restrict__ n_cigar, const int64_t *__restrict__ cigar_off,
+    const uint32_t *__restrict__ cigar, int min_gap, int min_mapq, int32_t *__restrict__ mbases,
+    int32_t *__restrict__ qinfer, int32_t *__restrict__ blk_first, int32_t *__restrict__ blk_last,
+    int32_t *__restrict__ gaps, uint32_t *__restrict__ gap_count, uint32_t gap_cap) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (SCAN_BLOCK / WAVE) + (threadIdx.x >> 6)));
+    const long long nwaves = (long long)gridDim.x * (SCAN_BLOCK / WAVE);
+    const cquad_t pad = {OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD};
+    const long long last_rec = n_rec - 1;      // n_rec >= 1 (checked by the launcher)
+    const int half_gap = min_gap >> 1;
+
+    // fetch cursor (record, chunk): metadata is wave-uniform, loaded with scalar loads one record ahead of its use
+    long long fr = wave;
+    int fc = 0, fnq = 0;
+    const cquad_t *__restrict__ fq = reinterpret_cast<const cquad_t *>(cigar);
+    int f_nn = 0;
+    long long f_noff = 0;
+    auto f_request = [&](long long r) {
+        const long long rr = r < n_rec ? r : last_rec;
+        f_nn = n_cigar[rr];
+        f_noff = cigar_off[rr];
+    };
+    auto f_meta = [&]() {
+        fc = 0;
+        fnq = fr < n_rec ? (f_nn + 3) >> 2 : 0;
+        fq = reinterpret_cast<const cquad_t *>(cigar + f_noff);
+        f_request(fr + nwaves);
+    };
+    auto f_chunk = [&](cquad_t &dst) {          // load the chunk under the cursor into a ring slot, then step
+        const cquad_t *__restrict__ base = fq + fc;            // wave-uniform
+        if (fc + WAVE <= fnq) {
+            dst = base[lane];                   // full chunk: SGPR base + lane offset, no masking
+        } else {                                // last (partial) chunk of a record, or a record without ops
+            dst = pad;
+            if (fc + lane < fnq) dst = base[lane];
+        }
+        fc += WAVE;
+        if (fc >= fnq) {
+            fr += nwaves;
+            f_meta();
+        }
+    };
+    // process cursor
+    long long pr = wave;
+    int pc = 0, pnq = 0, p0 = 0;
+    bool gaps_on = false;
+    int p_nn = 0, p_npos = 0, p_nfm = 0;
+    auto p_request = [&](long long r) {
+        const long long rr = r < n_rec ? r : last_rec;
+        p_nn = n_cigar[rr];
+        p_npos = pos[rr];
+        p_nfm = flagmq[rr];
+    };
+    auto p_meta = [&]() {
+        pc = 0;
+        pnq = (p_nn + 3) >> 2;
+        p0 = p_npos;
+        gaps_on = ((p_nfm >> 16) & 0xff) >= min_mapq;
+        p_request(pr + nwaves);
+    };
+    f_request(fr);
+    p_request(pr);
+    f_meta();
+    p_meta();
+    cquad_t ring[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) f_chunk(ring[j]);
+
+    RingState st = {0, 0, 0, 0, 0, false};
+    while (pr < n_rec) {
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            if (pr >= n_rec) break;                     // wave-uniform: this wave's records are done
+            ring_chunk<FILTER>(ring[j], lane, st, gaps_on, min_gap, half_gap, (int)pr, pc, p0, gaps, gap_count, gap_cap);
+            pc += WAVE;
+            if (pc >= pnq) {                            // last chunk of the record: write its summary, move on
+                const int ms = wave_sum_dpp(st.msum);
+                const int qs = wave_sum_dpp(st.qsum);
+                if (lane == 0) {
+                    mbases[pr] = ms;
+                    qinfer[pr] = qs;
+                    blk_first[pr] = (st.carry_end > 0) ? p0 + st.first : -1;
+                    blk_last[pr] = (st.carry_end > 0) ? p0 + st.carry_end : -1;
+                }
+                st = {0, 0, 0, 0, 0, false};
+                pr += nwaves;
+                p_meta();
+            }
+            f_chunk(ring[j]);                           // refill the slot: in flight during the next BATCH - 1 chunks
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 (variant 13, "ring + counted waits")  k_cigar_scan_ring with the ring loads issued and awaited by hand.
+// The compiler's s_waitcnt insertion cannot see across the loop back-edge that exactly BATCH - 1 younger loads are in
+// flight when a slot is consumed, and drains the whole ring (vmcnt(0)) once per round.  Here every f_chunk issues EXACTLY
+// ONE global_load_dwordx4 (inline asm; a partial or absent chunk loads from a clamped, always valid address and is masked
+// to padding when it is consumed), so the slot consumed next is always the oldest outstanding load and
+// `s_waitcnt vmcnt(BATCH - 1)` is exact.  Vector-memory operations the compiler issues on its own (record summaries, gap
+// rows) only make either side's count conservative: completion is in order, so "at most N outstanding" still implies the
+// awaited operation is done.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void ring_wait(cquad_t &slot) {
+    if (N == 7) asm volatile("s_waitcnt vmcnt(7)" : "+v"(slot));
+    else if (N == 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(slot));
+    else if (N == 5) asm volatile("s_waitcnt vmcnt(5)" : "+v"(slot));
+    else if (N == 11) asm volatile("s_waitcnt vmcnt(11)" : "+v"(slot));
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(slot));
+}
+
+template <int BATCH, bool FILTER>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_ring_asm(
+    long long n_rec, const int32_t *__restrict__ pos, const int32_t *__restrict__ flagmq,
+    const int32_t *__restrict__ n_cigar, const int64_t *__restrict__ cigar_off,
+    const uint32_t *__restrict__ cigar, int min_gap, int min_mapq, int32_t *__restrict__ mbases,
+    int32_t *__restrict__ qinfer, int32_t *__restrict__ blk_first, int32_t *__restrict__ blk_last,
+    int32_t *__restrict__ gaps, uint32_t *__restrict__ gap_count, uint32_t gap_cap) {
+    const int lane = threadIdx.x & 63;
+    const int lane16 = lane << 4;
+    const long long wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (SCAN_BLOCK / WAVE) + (threadIdx.x >> 6)));
+    const long long nwaves = (long long)gridDim.x * (SCAN_BLOCK / WAVE);
+    const cquad_t pad = {OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD};
+    const long long last_rec = n_rec - 1;      // n_rec >= 1 (checked by the launcher)
+    const int half_gap = min_gap >> 1;
+    const cquad_t *dummy = reinterpret_cast<const cquad_t *>(cigar);       // 16 readable bytes for chunks that do not exist
+
+    long long fr = wave;
+    int fc = 0, fnq = 0;
+    const cquad_t *__restrict__ fq = reinterpret_cast<const cquad_t *>(cigar);
+    int f_nn = 0;
+    long long f_noff = 0;
+    auto f_request = [&](long long r) {
+        const long long rr = r < n_rec ? r : last_rec;
+        f_nn = n_cigar[rr];
+        f_noff = cigar_off[rr];
+    };
+    auto f_meta = [&]() {
+        fc = 0;
+        fnq = fr < n_rec ? (f_nn + 3) >> 2 : 0;
+        fq = reinterpret_cast<const cquad_t *>(cigar + f_noff);
+        f_request(fr + nwaves);
+    };
+    auto f_chunk = [&](cquad_t &dst) {          // exactly one load per call
+        const cquad_t *base = fq + fc;          // wave-uniform
+        int voff = lane16;
+        if (fc + WAVE > fnq) {                  // (wave-uniform) partial or absent chunk: clamp to the last valid quad
+            const int nvalid = fnq - fc;
+            if (nvalid > 0) {
+                voff = min(lane, nvalid - 1) << 4;
+            } else {
+                base = dummy;
+                voff = 0;
+            }
+        }
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base));    // no "memory" clobber: it
+                                                     // would stop the compiler from using scalar loads for the metadata
+        fc += WAVE;
+        if (fc >= fnq) {
+            fr += nwaves;
+            f_meta();
+        }
+    };
+    long long pr = wave;
+    int pc = 0, pnq = 0, p0 = 0;
+    bool gaps_on = false;
+    int p_nn = 0, p_npos = 0, p_nfm = 0;
+    auto p_request = [&](long long r) {
+        const long long rr = r < n_rec ? r : last_rec;
+        p_nn = n_cigar[rr];
+        p_npos = pos[rr];
+        p_nfm = flagmq[rr];
+    };
+    auto p_meta = [&]() {
+        pc = 0;
+        pnq = (p_nn + 3) >> 2;
+        p0 = p_npos;
+        gaps_on = ((p_nfm >> 16) & 0xff) >= min_mapq;
+        p_request(pr + nwaves);
+    };
+    f_request(fr);
+    p_request(pr);
+    f_meta();
+    p_meta();
+    cquad_t ring[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) f_chunk(ring[j]);
+
+    RingState st = {0, 0, 0, 0, 0, false};
+    while (pr < n_rec) {
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            if (pr >= n_rec) break;                     // wave-uniform: this wave's records are done
+            ring_wait<BATCH - 1>(ring[j]);              // the oldest outstanding load is this slot's
+            cquad_t q = ring[j];
+            if (pc + WAVE > pnq) {                      // (wave-uniform) last chunk of the record: lanes past its end are padding
+                asm volatile("");                       // keep this a branch: selects on every chunk would cost 6 instructions
+                const bool valid = pc + lane < pnq;
+                q[0] = valid ? q[0] : pad[0];
+                q[1] = valid ? q[1] : pad[1];
+                q[2] = valid ? q[2] : pad[2];
+                q[3] = valid ? q[3] : pad[3];
+            }
+            ring_chunk<FILTER>(q, lane, st, gaps_on, min_gap, half_gap, (int)pr, pc, p0, gaps, gap_count, gap_cap);
+            pc += WAVE;
+            if (pc >= pnq) {
+                const int ms = wave_sum_dpp(st.msum);
+                const int qs = wave_sum_dpp(st.qsum);
+                if (lane == 0) {
+                    mbases[pr] = ms;
+                    qinfer[pr] = qs;
+                    blk_first[pr] = (st.carry_end > 0) ? p0 + st.first : -1;
+                    blk_last[pr] = (st.carry_end > 0) ? p0 + st.carry_end : -1;
+                }
+                st = {0, 0, 0, 0, 0, false};
+                pr += nwaves;
+                p_meta();
+            }
+            f_chunk(ring[j]);                           // refill the slot
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)");                 // nothing may still be landing in registers when the wave ends
+}
+
 // Streaming-read probe: what a plain grid-stride 16-byte-per-lane read of the same CIGAR bytes achieves
 // (upper bound for any kernel that must touch every op once).
 __global__ __launch_bounds__(256) void k_stream_probe(const cquad_t *__restrict__ q, long long n_quads, uint32_t *__restrict__ out) {
@@ -779,9 +1122,9 @@ extern "C" int coral_time_stream_read(const uint32_t *cigar, long long n_words, 
     return CORAL_OK;
 }
 
-static int g_scan_variant = 3;   // 8 KiB per wave in flight: best on average over the boxes measured (profiles/r01_scan_variants.md)
+static int g_scan_variant = 7;   // 8 KiB per wave in flight + conservative gap filter: best in-situ launch time (profiles/r01_scan_variants.md)
 extern "C" int coral_set_scan_variant(int v) {
-    if (v < 1 || v > 9) return CORAL_ERR_ARG;
+    if (v < 1 || v > 14) return CORAL_ERR_ARG;
     g_scan_variant = v;
     return CORAL_OK;
 }
@@ -836,6 +1179,24 @@ extern "C" int coral_cigar_scan(const coral_records_t *rec, int32_t min_gap, int
         hipLaunchKernelGGL(k_cigar_scan_packed<4>, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
                            (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
                            (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
+#define LAUNCH_RING(B, F)                                                                                             \
+    hipLaunchKernelGGL((k_cigar_scan_ring<B, F>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream, \
+                       (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,        \
+                       (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap)
+#define LAUNCH_RING_ASM(B, F)                                                                                         \
+    hipLaunchKernelGGL((k_cigar_scan_ring_asm<B, F>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream, \
+                       (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,        \
+                       (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap)
+    else if (g_scan_variant == 13)
+        LAUNCH_RING_ASM(8, true);
+    else if (g_scan_variant == 14)
+        LAUNCH_RING_ASM(4, true);
+    else if (g_scan_variant == 10)
+        LAUNCH_RING(8, true);
+    else if (g_scan_variant == 11)
+        LAUNCH_RING(4, true);
+    else if (g_scan_variant == 12)
+        LAUNCH_RING(8, false);
     else if (g_scan_variant == 7)
         hipLaunchKernelGGL((k_cigar_scan_v2<8, false, true>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
                            (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,

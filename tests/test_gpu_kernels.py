@@ -6,6 +6,7 @@ import torch
 from coral_amd import synth
 
 pytestmark = pytest.mark.gpu
+DEFAULT_VARIANT = 7          # the library default (coral_kernels.hip: g_scan_variant)
 
 
 def _odd_records():
@@ -78,7 +79,7 @@ def case(request):
     return request.param, rec, HostRecords(rec), DeviceRecords(rec, "cuda:0")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14])
 def test_cigar_scan(case, variant):
     """Every variant of the scan kernel (first version, batched per-record 2/4/8 KiB, flat contiguous ranges, and the
     8 KiB one with the conservative per-chunk gap filter)."""
@@ -88,7 +89,7 @@ def test_cigar_scan(case, variant):
     try:
         res = kernels.cigar_scan(dr, 600, 20, gap_cap=64)       # small cap: exercises the overflow/retry path
     finally:
-        _lib.lib().coral_set_scan_variant(3)
+        _lib.lib().coral_set_scan_variant(DEFAULT_VARIANT)
     mb, qi = res.mbases.cpu().numpy(), res.qinfer.cpu().numpy()
     b0, b1 = res.blk_first.cpu().numpy(), res.blk_last.cpu().numpy()
     gaps = []
@@ -110,8 +111,9 @@ def test_cigar_scan(case, variant):
         assert len(gaps) == 5     # a, b(N), e, i x2
 
 
+@pytest.mark.parametrize("variant", [7, 13])
 @pytest.mark.parametrize("min_gap", [0, 1, 3, 299, 300, 301, 601, 1199, 5000])
-def test_cigar_scan_gap_filter_thresholds(min_gap):
+def test_cigar_scan_gap_filter_thresholds(min_gap, variant):
     """The filtered variant against the oracle's blocks for thresholds around the D/N lengths of the adversarial set
     (odd and even: the filter flags a lane at G > min_gap // 2)."""
     from coral_amd import kernels, _lib
@@ -119,11 +121,11 @@ def test_cigar_scan_gap_filter_thresholds(min_gap):
     from oracle.hostrecords import HostRecords
     rec = _adversarial_records(seed=17 + min_gap, n=120)
     host, dr = HostRecords(rec), DeviceRecords(rec, "cuda:0")
-    assert _lib.lib().coral_set_scan_variant(7) == 0, "variant 7 missing"
+    assert _lib.lib().coral_set_scan_variant(variant) == 0
     try:
         res = kernels.cigar_scan(dr, min_gap, 20)
     finally:
-        _lib.lib().coral_set_scan_variant(3)
+        _lib.lib().coral_set_scan_variant(DEFAULT_VARIANT)
     want = []
     for i in range(host.n):
         bl = host.blocks(i)

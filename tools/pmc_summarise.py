@@ -11,6 +11,12 @@ for d in sys.argv[1:]:
             k = r["Kernel_Name"]
             if "scan" in k or "probe" in k or "seg_" in k or "point_cover" in k:
                 agg[k.split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for tf in glob.glob(d + "/**/*_kernel_trace.csv", recursive=True):
+        with open(tf) as fp:
+            for r in csv.DictReader(fp):
+                k = r["Kernel_Name"]
+                if "scan" in k or "probe" in k or "seg_" in k or "point_cover" in k:
+                    agg[k.split("(")[0].replace("void ", "")]["~duration_us"].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
     names = sorted({c for k in agg for c in agg[k]})
     print("#", d)
     print("%-44s" % "kernel", " ".join("%26s" % c for c in names))
