@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=50000, help="reads in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of N > 1)")
     ap.add_argument("--shared-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--gc-policy", default="freeze", choices=["pause", "freeze", "none"],
+                    help="cyclic-GC handling around the build (coral_amd.infer_breakpoint_graph.build_graph_from_records); "
+                         "'freeze' is what the reconstruct command line uses")
     ap.add_argument("--scan-variant", type=int, default=0, help="A/B only: coral_set_scan_variant (0 = library default)")
     a = ap.parse_args()
 
@@ -83,7 +86,7 @@ def main():
 
     def step(i):
         prefix = os.path.join(work, "r%d_s%d" % (rank, i))
-        b = sharding.build_graph_sharded(dr, seeds, cn, prefix if rank == 0 else None)
+        b = sharding.build_graph_sharded(dr, seeds, cn, prefix if rank == 0 else None, gc_policy=a.gc_policy)
         return b
 
     kernels.PROFILE["scan_ms"] = []
@@ -94,8 +97,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    step_ms = []
     for i in range(a.steps):
+        ts = time.perf_counter()
         b = step(i)
+        step_ms.append(round((time.perf_counter() - ts) * 1e3, 1))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -119,7 +125,7 @@ def main():
                                    "cycle step skipped" % (cfg.name, cfg.n_reads, cfg.mean_len, len(cfg.seeds), len(cfg.windows)),
                        "records": int(dr.n_total), "cigar_ops": int(dr.total_ops_all), "amplicons": len(b.lr_graph),
                        "discordant_edges": sum(len(g.discordant_edges) for g in b.lr_graph),
-                       "generate_s": round(gen_s, 2), "parallelism": "records sharded over %d GPU(s)" % world,
+                       "generate_s": round(gen_s, 2), "step_ms": step_ms, "gc_policy": a.gc_policy, "parallelism": "records sharded over %d GPU(s)" % world,
                        "phase_ms_last_step": {k: round(v * 1e3, 1) for k, v in ibg.PHASE_SECONDS.items()}},
             "roofline": {"bound": "hbm", "kernel": SCAN_KERNEL_NAME.get(a.scan_variant, "variant %d" % a.scan_variant), "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": pmc_traffic(cfg, world, SCAN_KERNEL_NAME.get(a.scan_variant)), "launch_ms": scan_ms_avg,

@@ -31,6 +31,7 @@ import numpy as np
 
 import ctypes as C
 import os
+import weakref
 
 from . import _lib, global_names, kernels
 from .bpcluster import call_breakpoints, bpc2bp, cluster_bp_list
@@ -87,7 +88,7 @@ class _ChimericAlignments(dict):
 
     def __init__(self, owner, names_in_order):
         super().__init__(dict.fromkeys(names_in_order))
-        self._owner = owner
+        self._owner = weakref.proxy(owner)      # no reference cycle: the result is freed by reference counting, not by the GC
         self._names = names_in_order
         self._index_ = None
         self._made = []                      # keys holding a materialised value
@@ -1236,7 +1237,7 @@ class _SegIndexView:
     """``chimeric_alignments_seg[chr][cni] -> [read names]`` view over the sorted inverted index."""
 
     def __init__(self, owner):
-        self._o = owner
+        self._o = weakref.proxy(owner)
 
     def as_dict(self):
         o = self._o
@@ -1259,18 +1260,31 @@ PHASE_SECONDS: Dict[str, float] = {}      # wall time of every phase of the last
 
 
 def build_graph_from_records(records, seedfile, cn_seg, output_prefix=None, min_bp_support=1.0, output_bp=False,
-                             graph_class=BreakpointGraph):
+                             graph_class=BreakpointGraph, gc_policy="pause"):
     """The call sequence of reconstruct_graph (ibg:1349-1394) on already-decoded records.
 
-    The cyclic garbage collector is paused for the duration of the build: the build allocates millions of small
-    containers (read tuples, name sets) but no reference cycles, and every generation-2 sweep over them costs ~0.1 s."""
+    The build allocates a few hundred thousand small containers (read tuples, name sets) and no reference cycles, so the
+    cyclic garbage collector can only cost time here.  ``gc_policy``:
+      "pause"   (default) collector off during the build, back on afterwards; the first collection after the build still
+                walks every container of the result once (~25 ms at 2 M reads) and every later full collection walks it again;
+      "freeze"  as "pause", then ``gc.freeze()``: the result (and whatever else the process holds at that moment) moves to
+                the permanent generation and is never walked again; everything is still freed by reference counting.
+                What the command line (reconstruct_graph) uses — meant for processes whose main job is this build;
+      "none"    leave the collector alone.
+    """
     import gc
+    if gc_policy not in ("pause", "freeze", "none"):
+        raise ValueError("gc_policy must be 'pause', 'freeze' or 'none'")
     gc_was_enabled = gc.isenabled()
-    gc.disable()
+    if gc_policy != "none":
+        gc.disable()
     try:
-        return _build_graph_from_records(records, seedfile, cn_seg, output_prefix, min_bp_support, output_bp, graph_class)
+        b2bn = _build_graph_from_records(records, seedfile, cn_seg, output_prefix, min_bp_support, output_bp, graph_class)
+        if gc_policy == "freeze":
+            gc.freeze()
+        return b2bn
     finally:
-        if gc_was_enabled:
+        if gc_was_enabled and gc_policy != "none":
             gc.enable()
 
 
@@ -1346,7 +1360,7 @@ def reconstruct_graph(args):
     from .records import DeviceRecords
     records = DeviceRecords(decode_bam(args.lr_bam), getattr(args, "device", "cuda:0"))
     return build_graph_from_records(records, args.cnv_seed, args.cn_seg, args.output_prefix, args.min_bp_support,
-                                    args.output_bp)
+                                    args.output_bp, gc_policy=getattr(args, "gc_policy", "freeze"))
 
 
 def print_complete_message():

@@ -81,14 +81,14 @@ def serve(dr):
             raise RuntimeError("unknown command %r" % (cmd,))
 
 
-def build_graph_sharded(dr, seedfile, cn_seg, output_prefix=None, min_bp_support=1.0, output_bp=False):
+def build_graph_sharded(dr, seedfile, cn_seg, output_prefix=None, min_bp_support=1.0, output_bp=False, gc_policy="pause"):
     """Graph build over sharded records: rank 0 returns the builder object, other ranks return None."""
     from . import infer_breakpoint_graph as ibg
     if dr.world == 1:
-        return ibg.build_graph_from_records(dr, seedfile, cn_seg, output_prefix, min_bp_support, output_bp)
+        return ibg.build_graph_from_records(dr, seedfile, cn_seg, output_prefix, min_bp_support, output_bp, gc_policy=gc_policy)
     if dr.rank == 0:
         try:
-            b = ibg.build_graph_from_records(dr, seedfile, cn_seg, output_prefix, min_bp_support, output_bp)
+            b = ibg.build_graph_from_records(dr, seedfile, cn_seg, output_prefix, min_bp_support, output_bp, gc_policy=gc_policy)
         finally:
             dist.broadcast_object_list([("done",)], src=0, group=dr.group)
         return b

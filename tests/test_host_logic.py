@@ -25,3 +25,29 @@ def test_strict_order_in_seeded_subprocess():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, cwd=root)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+
+
+def test_result_holds_no_reference_cycles(monkeypatch, tmp_path):
+    """The builder object must be freed by reference counting alone: a cyclic result would sit in memory (millions of
+    read tuples at full size) until a full garbage collection finds it."""
+    import gc
+    import weakref
+    from coral_amd import infer_breakpoint_graph as ibg, synth
+    from coral_amd.records import DeviceRecords
+    install_cpu_kernel_fakes(monkeypatch)
+    cfg, rec = synth.dataset("tiny", "cpu")
+    cn, seeds = str(tmp_path / "cn.bed"), str(tmp_path / "seeds.bed")
+    synth.write_cn_bed(cfg, cn)
+    synth.write_seed_bed(cfg, seeds)
+    dr = DeviceRecords(rec, "cpu")
+    gc.collect()
+    gc.disable()
+    try:
+        b = ibg.build_graph_from_records(dr, seeds, cn, None)
+        b.chimeric_alignments[next(iter(b.chimeric_alignments))]        # materialise a lazy entry
+        probe = weakref.ref(b)
+        graphs = weakref.ref(b.lr_graph[0])
+        del b
+        assert probe() is None and graphs() is None, "the result is kept alive by a reference cycle"
+    finally:
+        gc.enable()
