@@ -35,9 +35,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=50000, help="reads in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of N > 1)")
     ap.add_argument("--shared-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    ap.add_argument("--gc-policy", default="freeze", choices=["pause", "freeze", "none"],
-                    help="cyclic-GC handling around the build (coral_amd.infer_breakpoint_graph.build_graph_from_records); "
-                         "'freeze' is what the reconstruct command line uses")
+    ap.add_argument("--gc-policy", default="pause", choices=["pause", "freeze", "none"],
+                    help="cyclic-GC handling around the build (build_graph_from_records); 'pause' is the library and CLI default")
     ap.add_argument("--scan-variant", type=int, default=0, help="A/B only: coral_set_scan_variant (0 = library default)")
     a = ap.parse_args()
 

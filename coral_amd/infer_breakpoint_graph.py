@@ -1268,8 +1268,9 @@ def build_graph_from_records(records, seedfile, cn_seg, output_prefix=None, min_
       "pause"   (default) collector off during the build, back on afterwards; the first collection after the build still
                 walks every container of the result once (~25 ms at 2 M reads) and every later full collection walks it again;
       "freeze"  as "pause", then ``gc.freeze()``: the result (and whatever else the process holds at that moment) moves to
-                the permanent generation and is never walked again; everything is still freed by reference counting.
-                What the command line (reconstruct_graph) uses — meant for processes whose main job is this build;
+                the permanent generation and is never walked again; everything is still freed by reference counting
+                (the result holds no reference cycles).  For processes whose main job is this build; measured no faster
+                than "pause" once the result stopped being cyclic garbage;
       "none"    leave the collector alone.
     """
     import gc
@@ -1360,7 +1361,7 @@ def reconstruct_graph(args):
     from .records import DeviceRecords
     records = DeviceRecords(decode_bam(args.lr_bam), getattr(args, "device", "cuda:0"))
     return build_graph_from_records(records, args.cnv_seed, args.cn_seg, args.output_prefix, args.min_bp_support,
-                                    args.output_bp, gc_policy=getattr(args, "gc_policy", "freeze"))
+                                    args.output_bp, gc_policy=getattr(args, "gc_policy", "pause"))
 
 
 def print_complete_message():
