@@ -4,9 +4,9 @@
     python -m coral_amd.CoRAL reconstruct --lr_bam x.bam --cnv_seed seeds.bed --cn_seg cn.bed --output_prefix out \\
         --skip_cycle_decomp
 
-Only the `reconstruct` mode is re-implemented; the other modes of the reference (seed, hsr, plot,
-cycle2bed) are untouched and are delegated to the reference's own modules when they are importable (set
-CORAL_REFERENCE_SRC to the reference's src/ directory).  The cycle-decomposition step after the graph build is the
+The `reconstruct` mode and the `hsr` mode (§8(f) item 3) run on the MI355X path; the other modes of the
+reference (seed, plot, cycle2bed) are untouched and are delegated to the reference's own modules when they are
+importable (set CORAL_REFERENCE_SRC to the reference's src/ directory).  The cycle-decomposition step after the graph build is the
 reference's (Gurobi); it runs on the object this module returns.
 """
 import argparse
@@ -44,7 +44,16 @@ def build_parser():
                     action='store_true')
     rp.add_argument("--log_fn", help="Name of log file.")
     rp.add_argument("--device", help="GPU to use (MI355X build only option).", default="cuda:0")
-    for mode in ("seed", "hsr", "plot", "cycle2bed"):
+    hp = sub.add_parser("hsr", help="Detect possible integration points of ecDNA HSR amplifications.")     # CoRAL.py:112-120
+    hp.add_argument("--lr_bam", help="Sorted indexed long read bam file.", required=True)
+    hp.add_argument("--cycles", help="AmpliconSuite-formatted cycles file", required=True)
+    hp.add_argument("--cn_seg", help="Long read segmented whole genome CN calls (.bed or CNVkit .cns file).", required=True)
+    hp.add_argument("--output_prefix", help="Prefix of output file name.", required=True)
+    hp.add_argument("--normal_cov", help="Estimated diploid coverage.", required=True)
+    hp.add_argument("--bp_match_cutoff", help="Breakpoint matching cutoff.", type=int, default=100)
+    hp.add_argument("--bp_match_cutoff_clustering", help="Crude breakpoint matching cutoff for clustering.", type=int, default=2000)
+    hp.add_argument("--device", help="GPU to use (MI355X build only option).", default="cuda:0")
+    for mode in ("seed", "plot", "cycle2bed"):
         sub.add_parser(mode, help="(reference implementation; not part of the MI355X path)", add_help=False)
     return parser
 
@@ -72,7 +81,7 @@ def reconstruct_mode(args):
 
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
-    if argv and argv[0] in ("seed", "hsr", "plot", "cycle2bed"):
+    if argv and argv[0] in ("seed", "plot", "cycle2bed"):
         ref = os.environ.get("CORAL_REFERENCE_SRC")
         if not ref:
             raise SystemExit("mode '%s' is the reference's own code; set CORAL_REFERENCE_SRC to its src/ directory" % argv[0])
@@ -85,6 +94,11 @@ def main(argv=None):
     args = parser.parse_args(argv)
     if args.mode == "reconstruct":
         return reconstruct_mode(args)
+    if args.mode == "hsr":
+        print("Performing HSR mode with options:")              # CoRAL.py:34-38
+        print_args(args)
+        from coral_amd import hsr
+        return hsr.locate_hsrs(args)
     parser.print_help()
     return None
 

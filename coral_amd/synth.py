@@ -845,12 +845,55 @@ def _edge_alignments(cfg: SynthConfig) -> List[dict]:
     return sorted(out, key=lambda r: (r["tid"], r["pos"]))
 
 
+def _hsr_edge_alignments(cfg: SynthConfig) -> List[dict]:
+    """Hand-written three-piece reads for the ``hsr`` mode (/root/reference/src/hsr.py:117-147): integration junctions
+    between a locus outside the ecDNA and ecDNA segment ``a``, including the "skip a low-MAPQ middle piece" rule."""
+    M, I, D, N, S, H, P, EQ, X = range(9)
+    a = cfg.circles[0][0]                     # ecDNA segment (the hsr goldens use the first half of circle 0 as ecDNA)
+    t = a.tid
+    out_pos = cfg.windows[0][1] + 1_000_000   # inside the window (CN segments exist), far from every circle segment
+    mid_pos = cfg.windows[0][1] + 3_000_000
+    in_pos = a.start + 20_000
+    out = []
+
+    def three_piece(name, k, mq_mid, mq_out=60, mq_in=60, shift=0):
+        # query layout: [0, 3000) outside locus, [3000, 4000) middle piece, [4000, 7000) inside the ecDNA
+        A = (t, out_pos + shift + k + 1, 0, 0, 3000, 0, 4000, mq_out, 3)
+        B = (t, mid_pos + 7 * k + 1, 0, 3000, 1000, 0, 3000, mq_mid, 1)
+        Cc = (t, in_pos + shift + k + 1, 0, 4000, 3000, 0, 0, mq_in, 2)
+        return [dict(tid=t, pos=out_pos + shift + k, flag=0, mapq=mq_out, name=name, nm=3, cigar=[(M, 3000), (S, 4000)], sa=[B, Cc]),
+                dict(tid=t, pos=mid_pos + 7 * k, flag=2048, mapq=mq_mid, name=name, nm=1, cigar=[(H, 3000), (M, 1000), (H, 3000)], sa=[A, Cc]),
+                dict(tid=t, pos=in_pos + shift + k, flag=2048, mapq=mq_in, name=name, nm=2, cigar=[(H, 4000), (M, 3000)], sa=[A, B])]
+
+    # (1) low-MAPQ middle piece: the junction is called between pieces 0 and 2 (hsr.py:135-147)
+    for k in range(5):
+        out += three_piece("hsr_skip_%d" % k, k, mq_mid=5)
+    # (2) the same junction 60 bp away (same cluster, merged into the first refined breakpoint by the <= / < rule, hsr.py:160-163)
+    for k in range(3):
+        out += three_piece("hsr_near_%d" % k, k, mq_mid=3, shift=60)
+    # (3) middle piece with MAPQ 15: neither rule applies (>= 10 blocks the skip, < 20 blocks the adjacent pairs)
+    for k in range(3):
+        out += three_piece("hsr_mid15_%d" % k, k, mq_mid=15, shift=5000)
+    # (4) middle piece with MAPQ 60 outside the ecDNA: only the adjacent pair (1, 2) is a junction (hsr.py:122-131)
+    for k in range(4):
+        out += three_piece("hsr_adj_%d" % k, k, mq_mid=60, shift=9000)
+    # (5) outside piece with MAPQ 19: nothing is called
+    for k in range(2):
+        out += three_piece("hsr_lowout_%d" % k, k, mq_mid=5, mq_out=19, shift=13000)
+    return sorted(out, key=lambda r: (r["tid"], r["pos"]))
+
+
 def dataset(name: str, device="cpu") -> Tuple[SynthConfig, Records]:
     """Named data set = configuration + records ('tiny_edge' = 'tiny' plus hand-written corner-case records)."""
     if name == "tiny_edge":
         cfg = named_config("tiny")
         cfg.name = "tiny_edge"
         rec = merge_sorted(generate(cfg, "cpu"), records_from_alignments(_edge_alignments(cfg)))
+        return cfg, (rec if str(device) == "cpu" else rec.to(device))
+    if name == "hsr_edge":
+        cfg = named_config("tiny")
+        cfg.name = "hsr_edge"
+        rec = merge_sorted(generate(cfg, "cpu"), records_from_alignments(_hsr_edge_alignments(cfg)))
         return cfg, (rec if str(device) == "cpu" else rec.to(device))
     cfg = named_config(name)
     return cfg, generate(cfg, device)

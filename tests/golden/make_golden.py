@@ -34,6 +34,10 @@ E2E_CASES = [
 ]
 
 
+# the hsr mode (oracle/refharness/run_reference_hsr.py): (data set, --normal_cov)
+HSR_CASES = [("tiny", "4"), ("small", "8"), ("ultra", "10"), ("hsr_edge", "4"), ("tiny_edge", "2")]
+
+
 def jsonable(o):
     if isinstance(o, (set, frozenset)):
         return {"__set__": sorted((jsonable(x) for x in o), key=lambda v: json.dumps(v))}
@@ -198,8 +202,18 @@ def main():
         cmd = [sys.executable, "-m", "oracle.refharness.run_reference", cfg, out] + extra
         print(" ".join(cmd), flush=True)
         subprocess.run(cmd, cwd=ROOT, env=env, check=True, stdout=subprocess.DEVNULL)
+    hsr_only()
     print("done")
 
 
+def hsr_only():
+    env = dict(os.environ, PYTHONHASHSEED="0")
+    for cfg, cov in HSR_CASES:
+        out = os.path.join(HERE, "hsr_%s_%s.json" % (cfg, cov))
+        cmd = [sys.executable, "-m", "oracle.refharness.run_reference_hsr", cfg, cov, out]
+        print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, cwd=ROOT, env=env, check=True, stdout=subprocess.DEVNULL)
+
+
 if __name__ == "__main__":
-    main()
+    hsr_only() if sys.argv[1:] == ["hsr"] else main()

@@ -48,3 +48,32 @@ def test_cli_reconstruct_from_bam_matches_golden(golden_dir, tmp_path):
         compare_graph_text(open(prefix + name[3:]).read(), text)
     log = open(tmp_path / "run.log").read()
     assert "LR normal cov" in log and "Wrote breakpoint graph" in log
+
+
+def test_parser_accepts_reference_hsr_flags():
+    a = CoRAL.build_parser().parse_args(["hsr", "--lr_bam", "x.bam", "--cycles", "c.bed", "--cn_seg", "cn.bed",
+                                         "--output_prefix", "o", "--normal_cov", "31.5"])
+    assert a.mode == "hsr" and a.normal_cov == "31.5" and a.bp_match_cutoff == 100 and a.bp_match_cutoff_clustering == 2000
+
+
+@pytest.mark.gpu
+def test_cli_hsr_from_bam_matches_golden(golden_dir, tmp_path):
+    """BAM file on disk -> native decode -> K3 -> junction candidates -> stdout of the reference's hsr mode."""
+    from coral_amd import bam
+    from oracle.refharness.run_reference_hsr import hsr_inputs
+    cfg, rec, ecdna = hsr_inputs("hsr_edge")
+    bam_path = str(tmp_path / "x.bam")
+    bam.write_bam(rec, bam_path, seed=cfg.seed)
+    cn, cyc = str(tmp_path / "cn.bed"), str(tmp_path / "ecdna.bed")
+    synth.write_cn_bed(cfg, cn)
+    with open(cyc, "w") as fp:
+        for c, s, e in ecdna:
+            fp.write("%s\t%d\t%d\t+\t1\tTrue\t1.000000\n" % (c, s, e))
+    r = subprocess.run([sys.executable, "-m", "coral_amd.CoRAL", "hsr", "--lr_bam", bam_path, "--cycles", cyc, "--cn_seg", cn,
+                        "--output_prefix", "golden", "--normal_cov", "4"], cwd=str(tmp_path),
+                       env=dict(os.environ, PYTHONHASHSEED="0", PYTHONPATH=ROOT), capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    with open(os.path.join(golden_dir, "hsr_hsr_edge_4.json")) as fp:
+        gold = json.load(fp)
+    assert r.stdout.endswith(gold["stdout"])
+    assert os.path.exists(tmp_path / "integration_sites_golden.png")

@@ -1,0 +1,108 @@
+"""hsr mode: the CPU oracle and the product's host logic against goldens produced by the REAL
+reference (/root/reference/src/hsr.py run by oracle/refharness/run_reference_hsr.py, fixtures tests/golden/hsr_*.json)."""
+import contextlib
+import io
+import json
+import os
+import types
+
+import pytest
+
+from coral_amd import synth
+from oracle import hsr_oracle
+from oracle.hostrecords import HostRecords
+from oracle.refharness.run_reference import records_digest
+from oracle.refharness.run_reference_hsr import hsr_inputs
+from tests.product_check import install_cpu_kernel_fakes
+
+CASES = [("tiny", "4"), ("small", "8"), ("ultra", "10"), ("hsr_edge", "4"), ("tiny_edge", "2")]
+
+
+def _plain(o):
+    if isinstance(o, (list, tuple)):
+        return [_plain(x) for x in o]
+    if isinstance(o, (set, frozenset)):
+        return sorted(_plain(x) for x in o)
+    if hasattr(o, "item"):
+        return o.item()
+    return o
+
+
+def _load(golden_dir, case, cov, tmp_path):
+    with open(os.path.join(golden_dir, "hsr_%s_%s.json" % (case, cov))) as fp:
+        gold = json.load(fp)
+    cfg, rec, ecdna = hsr_inputs(case)
+    assert records_digest(rec) == gold["records_sha256"], "synthetic generator drifted from the golden inputs"
+    assert ecdna == gold["ecdna"]
+    cn = str(tmp_path / "cn.bed")
+    synth.write_cn_bed(cfg, cn)
+    cyc = str(tmp_path / "ecdna.bed")
+    with open(cyc, "w") as fp:
+        fp.write("#chr\tstart\tend\torientation\tcycle_id\tiscyclic\tweight\n")
+        for c, s, e in ecdna:
+            fp.write("%s\t%d\t%d\t+\t1\tTrue\t1.000000\n" % (c, s, e))
+    return gold, cfg, rec, ecdna, cn, cyc
+
+
+def _golden_stdout_lines(gold):
+    return [ln for ln in gold["stdout"].split("\n") if ln and not ln.startswith("Created ")]
+
+
+@pytest.mark.parametrize("case,cov", CASES)
+def test_oracle_matches_reference(case, cov, golden_dir, tmp_path):
+    gold, cfg, rec, ecdna, cn, _ = _load(golden_dir, case, cov, tmp_path)
+    host = HostRecords(rec)
+    if gold["raises"]:
+        with pytest.raises(KeyError) as ei:
+            hsr_oracle.locate_hsrs(host, ecdna, cn, cov)
+        assert [type(ei.value).__name__, [str(a) for a in ei.value.args]] == gold["raises"]
+        return
+    out = hsr_oracle.locate_hsrs(host, ecdna, cn, cov)
+    assert out["stdout_lines"] == _golden_stdout_lines(gold)
+    assert _plain(out["candidates"]) == gold["candidates"]
+    assert out["clusters"] == gold["clusters"]
+    assert _plain([[c[0], c[1], c[2], c[3]] for c in out["calls"]]) == gold["bpc2bp"]
+    assert out["points"] == gold["points"]
+
+
+@pytest.mark.parametrize("case,cov", CASES)
+def test_product_host_logic_matches_reference(case, cov, golden_dir, tmp_path, monkeypatch):
+    """coral_amd.hsr.locate_hsrs on the CPU stand-ins of the device kernels (tests only) — same stdout, candidates, calls and
+    plotted points as the reference; the -m gpu twin runs it on the real kernels."""
+    from coral_amd import hsr
+    from coral_amd.records import DeviceRecords
+    install_cpu_kernel_fakes(monkeypatch)
+    gold, cfg, rec, ecdna, cn, cyc = _load(golden_dir, case, cov, tmp_path)
+    _check_product(hsr, DeviceRecords(rec, "cpu"), gold, cn, cyc, cov, tmp_path, monkeypatch)
+
+
+def _check_product(hsr, dr, gold, cn, cyc, cov, tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    args = types.SimpleNamespace(lr_bam=None, cycles=cyc, cn_seg=cn, output_prefix="golden", normal_cov=cov,
+                                 bp_match_cutoff=100, bp_match_cutoff_clustering=2000)
+    buf = io.StringIO()
+    if gold["raises"]:
+        with contextlib.redirect_stdout(buf), pytest.raises(KeyError) as ei:
+            hsr.locate_hsrs(args, records=dr)
+        assert [type(ei.value).__name__, [str(a) for a in ei.value.args]] == gold["raises"]
+        assert buf.getvalue() == gold["stdout"]
+        return
+    with contextlib.redirect_stdout(buf):
+        res = hsr.locate_hsrs(args, records=dr)
+    assert buf.getvalue() == gold["stdout"]
+    assert _plain(res.candidates) == gold["candidates"]
+    assert res.cluster_sizes == gold["clusters"]
+    thr = float(cov) * 0.5
+    accepted = [g[:3] for g in gold["bpc2bp"] if len({tuple(t) for t in g[1]}) >= thr]
+    assert _plain(res.calls) == accepted
+    assert res.points == gold["points"]
+    assert os.path.exists(tmp_path / "integration_sites_golden.png") == gold["png_written"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,cov", CASES)
+def test_product_on_gpu_matches_reference(case, cov, golden_dir, tmp_path, monkeypatch):
+    from coral_amd import hsr
+    from coral_amd.records import DeviceRecords
+    gold, cfg, rec, ecdna, cn, cyc = _load(golden_dir, case, cov, tmp_path)
+    _check_product(hsr, DeviceRecords(rec, "cuda:0"), gold, cn, cyc, cov, tmp_path, monkeypatch)
