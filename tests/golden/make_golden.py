@@ -38,6 +38,10 @@ E2E_CASES = [
 HSR_CASES = [("tiny", "4"), ("small", "8"), ("ultra", "10"), ("hsr_edge", "4"), ("tiny_edge", "2")]
 
 
+# coverage track of the plot mode (oracle/refharness/run_reference_plotcov.py): (data set, region)
+PLOTCOV_CASES = [("tiny", None), ("tiny", "chr8:72000000-72050000"), ("tiny_edge", "chr8:72090000-72125001"), ("ultra", None)]
+
+
 def jsonable(o):
     if isinstance(o, (set, frozenset)):
         return {"__set__": sorted((jsonable(x) for x in o), key=lambda v: json.dumps(v))}
@@ -215,5 +219,19 @@ def hsr_only():
         subprocess.run(cmd, cwd=ROOT, env=env, check=True, stdout=subprocess.DEVNULL)
 
 
+def plotcov_only():
+    for cfg, region in PLOTCOV_CASES:
+        out = os.path.join(HERE, "plotcov_%s%s.json" % (cfg, "_region" if region else ""))
+        cmd = [sys.executable, "-m", "oracle.refharness.run_reference_plotcov", cfg, out] + ([region] if region else [])
+        print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, cwd=ROOT, check=True, stdout=subprocess.DEVNULL)
+
+
 if __name__ == "__main__":
-    hsr_only() if sys.argv[1:] == ["hsr"] else main()
+    if sys.argv[1:] == ["hsr"]:
+        hsr_only()
+    elif sys.argv[1:] == ["plotcov"]:
+        plotcov_only()
+    else:
+        main()
+        plotcov_only()
