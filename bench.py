@@ -20,8 +20,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-# name of the kernel behind coral_cigar_scan per coral_set_scan_variant value (0 = library default = 7)
-SCAN_KERNEL_NAME = {0: "k_cigar_scan_v2<8, false, true>", 7: "k_cigar_scan_v2<8, false, true>", 3: "k_cigar_scan_v2<8, false, false>",
+# name of the kernel behind coral_cigar_scan per coral_set_scan_variant value (0 = library default = 15)
+SCAN_KERNEL_NAME = {0: "k_cigar_scan_v2<8, false, true, 8>", 15: "k_cigar_scan_v2<8, false, true, 8>", 7: "k_cigar_scan_v2<8, false, true, 1>", 3: "k_cigar_scan_v2<8, false, false, 1>",
                     13: "k_cigar_scan_ring_asm<8, true>", 10: "k_cigar_scan_ring<8, true>", 8: "k_cigar_scan_packed<8>"}
 
 

@@ -205,7 +205,9 @@ __device__ __forceinline__ int wave_sum_dpp(int x) {
 // in this chunk is <= G(l) + G(l + 1) <= min_gap: nothing to report, and the running "end of the last aligned block" is
 // simply the one of the highest lane holding an aligned op.  Exact for every input; CIGARs of real reads trip the filter
 // only around actual large deletions and at the (padded) end of a record.
-template <int BATCH, bool LIGHT = false, bool FILTER = false>
+// TILE > 1: a wave takes TILE consecutive records at a time (tiles interleaved over the waves) instead of every
+// nwaves-th record, so its loads and its scalar metadata reads walk contiguous memory.
+template <int BATCH, bool LIGHT = false, bool FILTER = false, int TILE = 1>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
     long long n_rec, const int32_t *__restrict__ pos, const int32_t *__restrict__ flagmq,
     const int32_t *__restrict__ n_cigar, const int64_t *__restrict__ cigar_off,
@@ -223,7 +225,11 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
     // fetch cursor: (record, first chunk of the batch); runs one batch ahead of the arithmetic, across records.
     // Record metadata is wave-uniform (scalar loads) and requested ONE RECORD AHEAD of its use, so the wave never
     // stalls on the metadata -> first-quad dependency when it moves to its next record.
-    long long fr = wave;
+    auto next_rec = [&](long long r) -> long long {      // the record this wave handles after record r
+        if (TILE == 1) return r + nwaves;
+        return ((r + 1) % TILE != 0) ? r + 1 : r + 1 + (nwaves - 1) * TILE;
+    };
+    long long fr = wave * TILE;
     int fc = 0, fnq = 0;
     const cquad_t *__restrict__ fq = reinterpret_cast<const cquad_t *>(cigar);
     int f_nn = 0;            // n_cigar / cigar_off of record fr + nwaves (requested earlier)
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
         fc = 0;
         fnq = fr < n_rec ? (f_nn + 3) >> 2 : 0;
         fq = reinterpret_cast<const cquad_t *>(cigar + f_noff);
-        f_request(fr + nwaves);
+        f_request(next_rec(fr));
     };
     auto f_fetch = [&](cquad_t (&dst)[BATCH]) {
 #pragma unroll
@@ -250,12 +256,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
     auto f_step = [&]() {
         fc += BATCH * WAVE;
         if (fc >= fnq) {
-            fr += nwaves;
+            fr = next_rec(fr);
             f_meta();
         }
     };
     // process cursor (its metadata is requested one record ahead as well)
-    long long pr = wave;
+    long long pr = wave * TILE;
     int pc = 0, pnq = 0, p0 = 0;
     bool gaps_on = false;
     int p_nn = 0, p_npos = 0, p_nfm = 0;
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
         pnq = (p_nn + 3) >> 2;
         p0 = p_npos;
         gaps_on = ((p_nfm >> 16) & 0xff) >= min_mapq;
-        p_request(pr + nwaves);
+        p_request(next_rec(pr));
     };
     f_request(fr);
     p_request(pr);
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
             }
             carry_ref = 0; carry_end = 0; msum = 0; qsum = 0; first = 0;
             tail_flagged = false;
-            pr += nwaves;
+            pr = next_rec(pr);
             p_meta();
         } else {
             pc += BATCH * WAVE;
@@ -1122,9 +1128,9 @@ extern "C" int coral_time_stream_read(const uint32_t *cigar, long long n_words, 
     return CORAL_OK;
 }
 
-static int g_scan_variant = 7;   // 8 KiB per wave in flight + conservative gap filter: best in-situ launch time (profiles/r01_scan_variants.md)
+static int g_scan_variant = 15;  // 8 KiB per wave in flight + conservative gap filter + tiles of 8 consecutive records per wave: best launch time (profiles/r01_scan_variants.md)
 extern "C" int coral_set_scan_variant(int v) {
-    if (v < 1 || v > 14) return CORAL_ERR_ARG;
+    if (v < 1 || v > 19) return CORAL_ERR_ARG;
     g_scan_variant = v;
     return CORAL_OK;
 }
@@ -1197,6 +1203,24 @@ extern "C" int coral_cigar_scan(const coral_records_t *rec, int32_t min_gap, int
         LAUNCH_RING(4, true);
     else if (g_scan_variant == 12)
         LAUNCH_RING(8, false);
+#define LAUNCH_TILED(B, L, T)                                                                                         \
+    hipLaunchKernelGGL((k_cigar_scan_v2<B, L, true, T>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream, \
+                       (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,        \
+                       (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap)
+    else if (g_scan_variant == 17)
+        LAUNCH_TILED(8, false, 4);
+    else if (g_scan_variant == 18)
+        LAUNCH_TILED(8, false, 16);
+    else if (g_scan_variant == 19)
+        LAUNCH_TILED(4, true, 8);            // diagnostic: loads and cursors only, tiled (outputs invalid)
+    else if (g_scan_variant == 15)
+        hipLaunchKernelGGL((k_cigar_scan_v2<8, false, true, 8>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
+                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
+                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
+    else if (g_scan_variant == 16)
+        hipLaunchKernelGGL((k_cigar_scan_v2<8, false, true, 32>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
+                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
+                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
     else if (g_scan_variant == 7)
         hipLaunchKernelGGL((k_cigar_scan_v2<8, false, true>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
                            (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,

@@ -13,12 +13,12 @@ print("records", dr.n, "alg bytes", dr.algorithmic_bytes(), flush=True)
 ms = C.c_float(0)
 scr = torch.zeros(4, dtype=torch.int32, device="cuda")
 for rep in range(2):
-    for v in (3, 5, 7, 8, 10, 13):
+    for v in (3, 5, 7, 13, 15, 19):
         assert L.coral_set_scan_variant(v) == 0
         kernels.cigar_scan(dr)
     for m in (1, 2):
         L.coral_set_probe_mode(m)
         _lib.check(L.coral_time_stream_read(dr.cigar.data_ptr(), dr.cigar.numel(), scr.data_ptr(), 1, C.byref(ms), dr.stream()), "probe")
-L.coral_set_scan_variant(7)
+L.coral_set_scan_variant(15)
 torch.cuda.synchronize()
 print("done", flush=True)
