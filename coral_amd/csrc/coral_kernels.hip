@@ -1074,6 +1074,164 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_ring_asm(
     asm volatile("s_waitcnt vmcnt(0)");                 // nothing may still be landing in registers when the wave ends
 }
 
+// ---------------------------------------------------------------------------------------------
+// K1 (variant 20, "tile stream")  a wave takes tiles of TILE consecutive records (as variant 15) and reads a tile as ONE
+// contiguous run of 16-byte quads: the records of a tile are adjacent in the CIGAR array, so every load is a full,
+// unmasked 1 KiB chunk (SGPR base + lane offset) except the tile's last one, and the loads never notice record
+// boundaries.  The arithmetic walks the same chunk stream; a chunk that holds a record boundary is processed once per
+// record piece with the other lanes masked to padding (quad-aligned boundaries: the layout pads every record).
+// Per-record metadata (op count, position, flag/MAPQ, next offset) is read with scalar loads one record ahead.
+// ---------------------------------------------------------------------------------------------
+template <int BATCH, int TILE, bool FILTER>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_tile(
+    long long n_rec, const int32_t *__restrict__ pos, const int32_t *__restrict__ flagmq,
+    const int32_t *__restrict__ n_cigar, const int64_t *__restrict__ cigar_off,
+    const uint32_t *__restrict__ cigar, int min_gap, int min_mapq, int32_t *__restrict__ mbases,
+    int32_t *__restrict__ qinfer, int32_t *__restrict__ blk_first, int32_t *__restrict__ blk_last,
+    int32_t *__restrict__ gaps, uint32_t *__restrict__ gap_count, uint32_t gap_cap) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (SCAN_BLOCK / WAVE) + (threadIdx.x >> 6)));
+    const long long nwaves = (long long)gridDim.x * (SCAN_BLOCK / WAVE);
+    const cquad_t pad = {OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD};
+    const int half_gap = min_gap >> 1;
+    const long long n_tiles = (n_rec + TILE - 1) / TILE;       // n_rec >= 1 (checked by the launcher)
+    const long long last_tile = n_tiles - 1;
+    const cquad_t *__restrict__ qbase = reinterpret_cast<const cquad_t *>(cigar);
+
+    // ---- fetch cursor: (tile, quad offset inside the tile); a tile has max(1, ceil(quads / 64)) chunks
+    long long ft = wave;
+    const cquad_t *__restrict__ fbase = qbase;
+    int fq = 0, flen = 0;                     // next quad to fetch / quads of the tile
+    long long f_a = 0, f_b = 0;               // op offsets of the first record of tile ft + nwaves and of the tile after it
+    auto f_request = [&](long long t) {
+        const long long tt = t < n_tiles ? t : last_tile;
+        const long long r1 = (tt + 1) * TILE;
+        f_a = cigar_off[tt * TILE];
+        f_b = cigar_off[r1 < n_rec ? r1 : n_rec];
+    };
+    auto f_meta = [&]() {
+        fq = 0;
+        flen = ft < n_tiles ? (int)((f_b - f_a) >> 2) : 0;
+        fbase = qbase + (f_a >> 2);
+        f_request(ft + nwaves);
+    };
+    auto f_chunk = [&](cquad_t &dst) {
+        const cquad_t *__restrict__ base = fbase + fq;          // wave-uniform
+        if (fq + WAVE <= flen) {
+            dst = base[lane];
+        } else {
+            dst = pad;
+            if (fq + lane < flen) dst = base[lane];
+        }
+        fq += WAVE;
+        if (fq >= flen) {
+            ft += nwaves;
+            f_meta();
+        }
+    };
+    // ---- process cursor: tile, chunk, and the record the chunk stream is currently inside
+    long long pt = wave;
+    int pq = 0, plen = 0;                     // first quad of the current chunk / quads of the tile (tile-relative)
+    long long p_a = 0, p_b = 0;               // as f_a / f_b for the process cursor
+    long long tile_q0 = 0;                    // absolute quad of the tile start
+    auto t_request = [&](long long t) {
+        const long long tt = t < n_tiles ? t : last_tile;
+        const long long r1 = (tt + 1) * TILE;
+        p_a = cigar_off[tt * TILE];
+        p_b = cigar_off[r1 < n_rec ? r1 : n_rec];
+    };
+    long long pr = wave * TILE, tile_end_rec = 0;              // current record, one past the tile's last record
+    int rs = 0, re = 0, p0 = 0;               // the record's first quad and one past its last real quad (tile-relative)
+    bool gaps_on = false;
+    int r_nn = 0, r_pos = 0, r_fm = 0;        // metadata of record pr + 1 ... requested one record ahead
+    long long r_off = 0, r_noff = 0;
+    const long long last_rec = n_rec - 1;
+    auto r_request = [&](long long r) {
+        const long long rr = r < n_rec ? r : last_rec;
+        r_nn = n_cigar[rr];
+        r_pos = pos[rr];
+        r_fm = flagmq[rr];
+        r_off = cigar_off[rr];
+    };
+    auto r_meta = [&]() {                      // enter record pr (values requested earlier), request the next one
+        rs = (int)((r_off >> 2) - tile_q0);
+        re = rs + ((r_nn + 3) >> 2);
+        p0 = r_pos;
+        gaps_on = ((r_fm >> 16) & 0xff) >= min_mapq;
+        r_request(pr + 1);
+    };
+    auto t_meta = [&]() {                      // enter tile pt
+        pq = 0;
+        tile_q0 = p_a >> 2;
+        plen = pt < n_tiles ? (int)((p_b - p_a) >> 2) : 0;
+        pr = pt * TILE;
+        tile_end_rec = (pt + 1) * TILE < n_rec ? (pt + 1) * TILE : n_rec;
+        t_request(pt + nwaves);
+        r_request(pr);
+        r_meta();
+    };
+    f_request(ft);
+    t_request(pt);
+    f_meta();
+    t_meta();
+    cquad_t cur[BATCH], nxt[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) f_chunk(cur[j]);
+
+    RingState st = {0, 0, 0, 0, 0, false};
+    while (pt < n_tiles) {
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) asm volatile("" : "+v"(cur[j]));     // wait for this batch before issuing the next
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) f_chunk(nxt[j]);
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            if (pt >= n_tiles) break;                   // wave-uniform: this wave's tiles are done
+            const int cend = pq + WAVE;
+            // every record piece inside the chunk [pq, cend)
+            for (;;) {
+                const bool in_tile = pr < tile_end_rec;
+                if (!in_tile) break;
+                const int lo = rs > pq ? rs : pq;
+                const int hi = re < cend ? re : cend;
+                if (hi > lo) {
+                    cquad_t q = cur[j];
+                    if (lo != pq || hi != cend) {        // (wave-uniform) the piece does not fill the chunk: pad the other lanes
+                        asm volatile("");
+                        const int x = pq + lane;
+                        const bool valid = x >= lo && x < hi;
+                        q[0] = valid ? q[0] : pad[0];
+                        q[1] = valid ? q[1] : pad[1];
+                        q[2] = valid ? q[2] : pad[2];
+                        q[3] = valid ? q[3] : pad[3];
+                    }
+                    ring_chunk<FILTER>(q, lane, st, gaps_on, min_gap, half_gap, (int)pr, pq - rs, p0, gaps, gap_count, gap_cap);
+                }
+                if (re > cend) break;                    // the record continues in the next chunk
+                // the record ends inside this chunk: write its summary, enter the next record
+                const int ms = wave_sum_dpp(st.msum);
+                const int qs = wave_sum_dpp(st.qsum);
+                if (lane == 0) {
+                    mbases[pr] = ms;
+                    qinfer[pr] = qs;
+                    blk_first[pr] = (st.carry_end > 0) ? p0 + st.first : -1;
+                    blk_last[pr] = (st.carry_end > 0) ? p0 + st.carry_end : -1;
+                }
+                st = {0, 0, 0, 0, 0, false};
+                ++pr;
+                r_meta();
+            }
+            pq = cend;
+            if (pq >= plen) {                            // last chunk of the tile
+                pt += nwaves;
+                t_meta();
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) cur[j] = nxt[j];
+    }
+}
+
 // Streaming-read probe: what a plain grid-stride 16-byte-per-lane read of the same CIGAR bytes achieves
 // (upper bound for any kernel that must touch every op once).
 __global__ __launch_bounds__(256) void k_stream_probe(const cquad_t *__restrict__ q, long long n_quads, uint32_t *__restrict__ out) {
@@ -1130,7 +1288,7 @@ extern "C" int coral_time_stream_read(const uint32_t *cigar, long long n_words, 
 
 static int g_scan_variant = 15;  // 8 KiB per wave in flight + conservative gap filter + tiles of 8 consecutive records per wave: best launch time (profiles/r01_scan_variants.md)
 extern "C" int coral_set_scan_variant(int v) {
-    if (v < 1 || v > 19) return CORAL_ERR_ARG;
+    if (v < 1 || v > 22) return CORAL_ERR_ARG;
     g_scan_variant = v;
     return CORAL_OK;
 }
@@ -1138,6 +1296,15 @@ extern "C" int coral_set_scan_variant(int v) {
 static int scan_grid(long long n_rec) {
     long long blocks = (n_rec + (SCAN_BLOCK / WAVE) - 1) / (SCAN_BLOCK / WAVE);
     const long long cap = 256 * 8;   // 256 CUs x 8 workgroups of 4 waves = 32 waves per CU
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+static int tile_grid(long long n_rec, int tile) {      // one wave per tile up to the resident-wave cap
+    const long long tiles = (n_rec + tile - 1) / tile;
+    long long blocks = (tiles + (SCAN_BLOCK / WAVE) - 1) / (SCAN_BLOCK / WAVE);
+    const long long cap = 256 * 8;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
@@ -1207,6 +1374,16 @@ extern "C" int coral_cigar_scan(const coral_records_t *rec, int32_t min_gap, int
     hipLaunchKernelGGL((k_cigar_scan_v2<B, L, true, T>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream, \
                        (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,        \
                        (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap)
+#define LAUNCH_TILE(B, T)                                                                                             \
+    hipLaunchKernelGGL((k_cigar_scan_tile<B, T, true>), dim3(tile_grid(rec->n_rec, T)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream, \
+                       (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,        \
+                       (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap)
+    else if (g_scan_variant == 20)
+        LAUNCH_TILE(8, 8);
+    else if (g_scan_variant == 21)
+        LAUNCH_TILE(8, 16);
+    else if (g_scan_variant == 22)
+        LAUNCH_TILE(4, 8);
     else if (g_scan_variant == 17)
         LAUNCH_TILED(8, false, 4);
     else if (g_scan_variant == 18)

@@ -79,7 +79,7 @@ def case(request):
     return request.param, rec, HostRecords(rec), DeviceRecords(rec, "cuda:0")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 21, 22])
 def test_cigar_scan(case, variant):
     """Every variant of the scan kernel (first version, batched per-record 2/4/8 KiB, flat contiguous ranges, and the
     8 KiB one with the conservative per-chunk gap filter)."""
@@ -111,7 +111,7 @@ def test_cigar_scan(case, variant):
         assert len(gaps) == 5     # a, b(N), e, i x2
 
 
-@pytest.mark.parametrize("variant", [7, 13, 15])
+@pytest.mark.parametrize("variant", [7, 13, 15, 20])
 @pytest.mark.parametrize("min_gap", [0, 1, 3, 299, 300, 301, 601, 1199, 5000])
 def test_cigar_scan_gap_filter_thresholds(min_gap, variant):
     """The filtered variant against the oracle's blocks for thresholds around the D/N lengths of the adversarial set
