@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--shared-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--gc-policy", default="pause", choices=["pause", "freeze", "none"],
                     help="cyclic-GC handling around the build (build_graph_from_records); 'pause' is the library and CLI default")
+    ap.add_argument("--mode", default="shard", choices=["shard", "samples"],
+                    help="N > 1: 'shard' (default) = ONE sample, records sharded over the GPUs, exchange over RCCL (strong scaling); "
+                         "'samples' = one independent sample per GPU, no collective on the data path (weak scaling, cohort use)")
     ap.add_argument("--scan-variant", type=int, default=0, help="A/B only: coral_set_scan_variant (0 = library default)")
     a = ap.parse_args()
 
@@ -77,15 +80,19 @@ def main():
     rec = synth.generate(cfg, dev, chunk_pieces=200000)
     torch.cuda.synchronize()
     gen_s = time.time() - t0
-    dr = sharding.shard_records(rec, rank, world, dev)          # world == 1: all records on this GPU
-    n_reads_total = cfg.n_reads
+    if a.mode == "samples" and world > 1:
+        dr = sharding.shard_records(rec, 0, 1, dev)             # every rank holds (and builds) a whole sample of its own
+        n_reads_total = cfg.n_reads * world
+    else:
+        dr = sharding.shard_records(rec, rank, world, dev)      # world == 1: all records on this GPU
+        n_reads_total = cfg.n_reads
     alg_bytes_local = dr.algorithmic_bytes()
     del rec
     torch.cuda.empty_cache()
 
     def step(i):
         prefix = os.path.join(work, "r%d_s%d" % (rank, i))
-        b = sharding.build_graph_sharded(dr, seeds, cn, prefix if rank == 0 else None, gc_policy=a.gc_policy)
+        b = sharding.build_graph_sharded(dr, seeds, cn, prefix if (rank == 0 or a.mode == "samples") else None, gc_policy=a.gc_policy)
         return b
 
     kernels.PROFILE["scan_ms"] = []
@@ -119,12 +126,14 @@ def main():
         out = {
             "metric": "reads/sec through breakpoint-graph build", "value": value, "unit": "reads/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+            "scaling": "weak" if (a.mode == "samples" and world > 1) else "strong", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
             "config": {"workload": "%s: %d reads x %d bp mean, %d seed intervals over %d chroms, full reconstruct incl. CN, "
                                    "cycle step skipped" % (cfg.name, cfg.n_reads, cfg.mean_len, len(cfg.seeds), len(cfg.windows)),
                        "records": int(dr.n_total), "cigar_ops": int(dr.total_ops_all), "amplicons": len(b.lr_graph),
                        "discordant_edges": sum(len(g.discordant_edges) for g in b.lr_graph),
-                       "generate_s": round(gen_s, 2), "step_ms": step_ms, "gc_policy": a.gc_policy, "parallelism": "records sharded over %d GPU(s)" % world,
+                       "generate_s": round(gen_s, 2), "step_ms": step_ms, "gc_policy": a.gc_policy,
+                       "parallelism": ("%d independent samples, one per GPU" % world) if (a.mode == "samples" and world > 1)
+                       else "records sharded over %d GPU(s)" % world,
                        "phase_ms_last_step": {k: round(v * 1e3, 1) for k, v in ibg.PHASE_SECONDS.items()}},
             "roofline": {"bound": "hbm", "kernel": SCAN_KERNEL_NAME.get(a.scan_variant, "variant %d" % a.scan_variant), "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": pmc_traffic(cfg, world, SCAN_KERNEL_NAME.get(a.scan_variant)), "launch_ms": scan_ms_avg,
