@@ -1710,12 +1710,16 @@ __device__ __forceinline__ int first_interval(const CandParams &P, int row) {
     return -1;
 }
 
-__device__ __forceinline__ bool pair_qualifies(const CandParams &P, int a, int b) {
-    if (P.mode == 1) {
-        const bool a1 = row_overlaps(P, a, P.int_tid[0], P.int_start[0], P.int_end[0]);
-        const bool a2 = row_overlaps(P, a, P.int_tid[1], P.int_start[1], P.int_end[1]);
-        const bool b1 = row_overlaps(P, b, P.int_tid[0], P.int_start[0], P.int_end[0]);
-        const bool b2 = row_overlaps(P, b, P.int_tid[1], P.int_start[1], P.int_end[1]);
+__device__ __forceinline__ bool pair_qualifies(const CandParams &P, int a, int b, int sel_index) {
+    if (P.mode == 1 || P.mode == 2) {
+        // mode 1: the two intervals are [0] and [1]; mode 2 (several mode-1 queries in one launch): the selection carries an
+        // interval index per read after the read indices, and every read pairs that interval with the LAST one
+        const int k1 = P.mode == 1 ? 0 : P.sel[P.n_sel + sel_index];
+        const int k2 = P.mode == 1 ? 1 : P.n_int - 1;
+        const bool a1 = row_overlaps(P, a, P.int_tid[k1], P.int_start[k1], P.int_end[k1]);
+        const bool a2 = row_overlaps(P, a, P.int_tid[k2], P.int_start[k2], P.int_end[k2]);
+        const bool b1 = row_overlaps(P, b, P.int_tid[k1], P.int_start[k1], P.int_end[k1]);
+        const bool b2 = row_overlaps(P, b, P.int_tid[k2], P.int_start[k2], P.int_end[k2]);
         return (a1 && b2) || (b1 && a2);
     }
     const int ia = first_interval(P, a), ib = first_interval(P, b);
@@ -1759,7 +1763,7 @@ __global__ __launch_bounds__(256) void k_bp_candidates(CandParams P, int32_t *__
     for (int k = 0; k + 1 < n; ++k) {
         const int a = base + k, b = a + 1;
         const int gap = P.qs[b] - P.qe[a];
-        if (gap + P.cutoff >= 0 && P.mapq[a] >= P.min_mapq && P.mapq[b] >= P.min_mapq && pair_qualifies(P, a, b)) {
+        if (gap + P.cutoff >= 0 && P.mapq[a] >= P.min_mapq && P.mapq[b] >= P.min_mapq && pair_qualifies(P, a, b, i)) {
             used |= 1ull << k;
             if (WRITE) { if (w < cap) emit_candidate(P, a, b, k, k + 1, read, cand + (long long)w * 13, err); }
             ++w;
@@ -1769,7 +1773,7 @@ __global__ __launch_bounds__(256) void k_bp_candidates(CandParams P, int32_t *__
         const int a = base + k - 1, m = base + k, b = base + k + 1;
         if (((used >> (k - 1)) & 1ull) || ((used >> k) & 1ull)) continue;
         if (!(P.mapq[m] < P.gap_mapq && P.mapq[a] >= P.min_mapq && P.mapq[b] >= P.min_mapq)) continue;
-        if (pair_qualifies(P, a, b)) {
+        if (pair_qualifies(P, a, b, i)) {
             if (WRITE) { if (w < cap) emit_candidate(P, a, b, k - 1, k + 1, read, cand + (long long)w * 13, err); }
             ++w;
         }
@@ -1814,6 +1818,8 @@ extern "C" int coral_bp_candidates(const coral_chimeric_t *ct, int32_t n_sel, co
         !int_tid || !int_start || !int_end || (cap > 0 && !cand))
         return set_err(CORAL_ERR_ARG, "bp_candidates: null argument");
     if (mode == 1 && n_int != 2) return set_err(CORAL_ERR_ARG, "bp_candidates: mode 1 needs exactly two intervals");
+    if (mode == 2 && (n_int < 2 || !sel)) return set_err(CORAL_ERR_ARG, "bp_candidates: mode 2 needs a selection (reads, then interval index per read) and >= 2 intervals");
+    if (mode < 0 || mode > 2) return set_err(CORAL_ERR_ARG, "bp_candidates: unknown mode");
     if (!sel && n_sel != ct->n_reads) return set_err(CORAL_ERR_ARG, "bp_candidates: sel == NULL means all reads");
     CandParams P;
     P.n_sel = n_sel; P.sel = sel;

@@ -667,145 +667,149 @@ class bam_to_breakpoint_nanopore():
                 if not reach[c]:
                     del reach[c]
             refined, refined_bps = [], []
+            # every (chromosome, run of neighbouring segments) reached from this interval, in the reference's order
+            here = self.amplicon_intervals[cur]            # not modified before all groups are done (ibg:385-612)
+            plan = []
             for c in reach:
                 bins = sorted(reach[c])
-                groups, members, first = [], [], 0      # members: key ids whose sets the reference unions with |=
+                members, first = [], 0                      # members: key ids whose sets the reference unions with |=
                 for k in range(len(bins) - 1):
                     members.append(reach[c][bins[k]])
                     if bins[k + 1] - bins[k] > 2 or by[c][bins[k + 1]][1] - by[c][bins[k]][2] > self.max_seq_len:
-                        groups.append((bins[first], bins[k], members))
+                        plan.append((c, bins[first], bins[k], members))
                         first = k + 1
                         members = []
                 members.append(reach[c][bins[-1]])
-                groups.append((bins[first], bins[-1], members))
-                for (b0, b1, grp_keys) in groups:
-                    ns, ne = by[c][b0][1], by[c][b1][2]
-                    tgt = [c, ns, ne]
-                    here = self.amplicon_intervals[cur]
-                    reads = self._iteration_order(set_handle, grp_keys)          # set-of-str iteration order (Q21)
-                    cands = candidates_between(T, reads, (self._tid_of[c], ns, ne),
-                                               (self._tid_of[here[0]], here[1], here[2]), self._chr_rank, self.rec,
-                                               self.min_bp_match_cutoff_, 20)
-                    cands.read = T.name_id[cands.read]
-                    logging.debug(_t() + "\t\tFound %d reads connecting the two intervals." % len(cands))
-                    found = []
-                    for bp, tuples, st, ids in self._call_breakpoints(cands, advance_subcluster=False):
-                        k = self.addbp(bp, set(tuples), st, ccid, ids)
-                        if k not in found:
-                            found.append(k)
-                    inside, outside = [], []
-                    for k in found:
-                        bp = self.new_bp_list[k][:6]
-                        e1, e2 = [bp[0], bp[1], bp[1]], [bp[3], bp[4], bp[4]]
-                        try:
-                            if interval_overlap(e1, here) and interval_overlap(e2, tgt):
-                                inside.append([self.pos2cni(bp[3], bp[4])[0], bp[4], k])
-                            elif interval_overlap(e2, here) and interval_overlap(e1, tgt):
+                plan.append((c, bins[first], bins[-1], members))
+            # candidates of ALL groups in one launch: alignment2bp between each target run and the current interval
+            orders = [self._iteration_order(set_handle, keys) for (_, _, _, keys) in plan]     # set-of-str iteration order (Q21)
+            targets = [(self._tid_of[c], by[c][b0][1], by[c][b1][2]) for (c, b0, b1, _) in plan]
+            all_cands = kernels.bp_candidates_grouped(self.rec, T, orders, targets, (self._tid_of[here[0]], here[1], here[2]),
+                                                      self._chr_rank, self.min_bp_match_cutoff_, 20) if plan else []
+            for gi, (c, b0, b1, _) in enumerate(plan):
+                ns, ne = by[c][b0][1], by[c][b1][2]
+                tgt = [c, ns, ne]
+                cands = all_cands[gi]
+                cands.read = T.name_id[cands.read]
+                logging.debug(_t() + "\t\tFound %d reads connecting the two intervals." % len(cands))
+                found = []
+                for bp, tuples, st, ids in self._call_breakpoints(cands, advance_subcluster=False):
+                    k = self.addbp(bp, set(tuples), st, ccid, ids)
+                    if k not in found:
+                        found.append(k)
+                inside, outside = [], []
+                for k in found:
+                    bp = self.new_bp_list[k][:6]
+                    e1, e2 = [bp[0], bp[1], bp[1]], [bp[3], bp[4], bp[4]]
+                    try:
+                        if interval_overlap(e1, here) and interval_overlap(e2, tgt):
+                            inside.append([self.pos2cni(bp[3], bp[4])[0], bp[4], k])
+                        elif interval_overlap(e2, here) and interval_overlap(e1, tgt):
+                            inside.append([self.pos2cni(bp[0], bp[1])[0], bp[1], k])
+                        else:
+                            logging.warning(_t() + "\t\tExact breakpoint outside amplicon interval.")
+                            o1, o2 = interval_overlap(e1, tgt), interval_overlap(e2, tgt)
+                            if o1:
                                 inside.append([self.pos2cni(bp[0], bp[1])[0], bp[1], k])
                             else:
-                                logging.warning(_t() + "\t\tExact breakpoint outside amplicon interval.")
-                                o1, o2 = interval_overlap(e1, tgt), interval_overlap(e2, tgt)
-                                if o1:
-                                    inside.append([self.pos2cni(bp[0], bp[1])[0], bp[1], k])
-                                else:
-                                    outside.append([bp[0], self.pos2cni(bp[0], bp[1])[0], bp[1], k])
-                                if o2:
-                                    inside.append([self.pos2cni(bp[3], bp[4])[0], bp[4], k])
-                                else:
-                                    outside.append([bp[3], self.pos2cni(bp[3], bp[4])[0], bp[4], k])
-                        except Exception:
-                            pass
-                    if not found:
+                                outside.append([bp[0], self.pos2cni(bp[0], bp[1])[0], bp[1], k])
+                            if o2:
+                                inside.append([self.pos2cni(bp[3], bp[4])[0], bp[4], k])
+                            else:
+                                outside.append([bp[3], self.pos2cni(bp[3], bp[4])[0], bp[4], k])
+                    except Exception:
+                        pass
+                if not found:
+                    continue
+                inside.sort(key=lambda t: (t[0], t[1]))
+                outside.sort(key=lambda t: (chr_idx[t[0]], t[1], t[2]))
+                segs = by[c]
+                gain = self.cn_gain
+
+                def split_inside(k):
+                    nil, ncn = segs[inside[k + 1][0]][1], segs[inside[k + 1][0]][3]
+                    lir, lcn = segs[inside[k][0]][2], segs[inside[k][0]][3]
+                    amp = ncn >= gain or lcn >= gain
+                    dpos = inside[k + 1][1] - inside[k][1]
+                    return (inside[k + 1][0] - inside[k][0] > 2 or nil - lir > self.max_seq_len / 2 or
+                            dpos > self.max_seq_len or (not amp and nil - lir > 2 * D) or (not amp and dpos > 3 * D))
+
+                first = 0
+                for k in range(len(inside) - 1):
+                    if not split_inside(k):
                         continue
-                    inside.sort(key=lambda t: (t[0], t[1]))
-                    outside.sort(key=lambda t: (chr_idx[t[0]], t[1], t[2]))
-                    segs = by[c]
-                    gain = self.cn_gain
+                    f, z = inside[first], inside[k]
+                    lir = segs[z[0]][2]
+                    l = max((f[1] if not segs[f[0]][3] >= gain else segs[f[0]][1]) - D, segs[0][1])
+                    r = min((z[1] if not segs[z[0]][3] >= gain else lir) + D, segs[-1][2])
+                    if segs[f[0]][3] and f[1] - half > l:            # Q3: CN value used as a truth value
+                        l = f[1] - half
+                    if z[1] + half < r:
+                        r = z[1] + half
+                    if not self.pos2cni(c, l):
+                        l = segs[f[0]][1]
+                    if not self.pos2cni(c, r):
+                        r = lir
+                    refined.append([c, l, r, -1])
+                    refined_bps.append([inside[j][2] for j in range(first, k + 1)])
+                    first = k + 1
+                if inside:
+                    f, z = inside[first], inside[-1]
+                    l = max((f[1] if not segs[f[0]][3] >= gain else segs[f[0]][1]) - D, segs[0][1])
+                    r = min((z[1] if not segs[z[0]][3] >= gain else segs[z[0]][2]) + D, segs[-1][2])
+                    if f[1] - half > l:
+                        l = f[1] - half > l                         # Q2: the comparison result is stored
+                    if z[1] + half < r:
+                        r = z[1] + half
+                    if not self.pos2cni(c, l):
+                        l = segs[f[0]][1]
+                    if not self.pos2cni(c, r):
+                        r = segs[z[0]][2]
+                    refined.append([c, l, r, -1])
+                    refined_bps.append([inside[j][2] for j in range(first, len(inside))])
 
-                    def split_inside(k):
-                        nil, ncn = segs[inside[k + 1][0]][1], segs[inside[k + 1][0]][3]
-                        lir, lcn = segs[inside[k][0]][2], segs[inside[k][0]][3]
-                        amp = ncn >= gain or lcn >= gain
-                        dpos = inside[k + 1][1] - inside[k][1]
-                        return (inside[k + 1][0] - inside[k][0] > 2 or nil - lir > self.max_seq_len / 2 or
-                                dpos > self.max_seq_len or (not amp and nil - lir > 2 * D) or (not amp and dpos > 3 * D))
+                def split_outside(k):
+                    a, b = outside[k], outside[k + 1]
+                    nil, ncn = by[b[0]][b[1]][1], by[b[0]][b[1]][3]
+                    lir, lcn = by[a[0]][a[1]][2], by[a[0]][a[1]][3]
+                    amp = ncn >= gain or lcn >= gain
+                    return (b[0] != a[0] or b[1] - a[1] > 2 or nil - lir > self.max_seq_len / 2 or
+                            b[2] - a[2] > self.max_seq_len or (not amp and nil - lir > 2 * D) or
+                            (not amp and b[2] - a[2] > 3 * D))
 
-                    first = 0
-                    for k in range(len(inside) - 1):
-                        if not split_inside(k):
-                            continue
-                        f, z = inside[first], inside[k]
-                        lir = segs[z[0]][2]
-                        l = max((f[1] if not segs[f[0]][3] >= gain else segs[f[0]][1]) - D, segs[0][1])
-                        r = min((z[1] if not segs[z[0]][3] >= gain else lir) + D, segs[-1][2])
-                        if segs[f[0]][3] and f[1] - half > l:            # Q3: CN value used as a truth value
-                            l = f[1] - half
-                        if z[1] + half < r:
-                            r = z[1] + half
-                        if not self.pos2cni(c, l):
-                            l = segs[f[0]][1]
-                        if not self.pos2cni(c, r):
-                            r = lir
-                        refined.append([c, l, r, -1])
-                        refined_bps.append([inside[j][2] for j in range(first, k + 1)])
-                        first = k + 1
-                    if inside:
-                        f, z = inside[first], inside[-1]
-                        l = max((f[1] if not segs[f[0]][3] >= gain else segs[f[0]][1]) - D, segs[0][1])
-                        r = min((z[1] if not segs[z[0]][3] >= gain else segs[z[0]][2]) + D, segs[-1][2])
-                        if f[1] - half > l:
-                            l = f[1] - half > l                         # Q2: the comparison result is stored
-                        if z[1] + half < r:
-                            r = z[1] + half
-                        if not self.pos2cni(c, l):
-                            l = segs[f[0]][1]
-                        if not self.pos2cni(c, r):
-                            r = segs[z[0]][2]
-                        refined.append([c, l, r, -1])
-                        refined_bps.append([inside[j][2] for j in range(first, len(inside))])
-
-                    def split_outside(k):
-                        a, b = outside[k], outside[k + 1]
-                        nil, ncn = by[b[0]][b[1]][1], by[b[0]][b[1]][3]
-                        lir, lcn = by[a[0]][a[1]][2], by[a[0]][a[1]][3]
-                        amp = ncn >= gain or lcn >= gain
-                        return (b[0] != a[0] or b[1] - a[1] > 2 or nil - lir > self.max_seq_len / 2 or
-                                b[2] - a[2] > self.max_seq_len or (not amp and nil - lir > 2 * D) or
-                                (not amp and b[2] - a[2] > 3 * D))
-
-                    first = 0
-                    for k in range(len(outside) - 1):
-                        if not split_outside(k):
-                            continue
-                        f, z = outside[first], outside[k]
-                        lir = by[z[0]][z[1]][2]
-                        l = max((f[2] if not by[f[0]][f[1]][3] >= gain else by[f[0]][f[1]][1]) - D, by[f[0]][0][1])
-                        r = min((z[2] if not by[z[0]][z[1]][3] >= gain else lir) + D, by[z[0]][-1][2])
-                        if f[2] - half > l:
-                            l = f[2] - half
-                        if z[2] + half < r:
-                            r = z[2] + half
-                        if not self.pos2cni(f[0], l):
-                            l = by[f[0]][f[1]][1]
-                        if not self.pos2cni(z[0], r):
-                            r = lir
-                        refined.append([f[0], l, r, -1])
-                        refined_bps.append([])
-                        first = k + 1
-                    if outside:
-                        f, z = outside[first], outside[-1]
-                        l = max((f[2] if not by[f[0]][f[1]][3] >= gain else by[f[0]][f[1]][1]) - D, by[f[0]][0][1])
-                        r = min((z[2] if not by[z[0]][z[1]][3] >= gain else by[z[0]][z[1]][2]) + D, by[z[0]][-1][2])
-                        if f[2] - half > l:
-                            l = f[2] - half
-                        if z[2] + half < r:
-                            r = z[2] + half
-                        if not self.pos2cni(f[0], l):
-                            l = by[f[0]][f[1]][1]
-                        if not self.pos2cni(f[0], r):
-                            r = by[f[0]][z[1]][2]
-                        refined.append([f[0], l, r, -1])
-                        refined_bps.append([])
+                first = 0
+                for k in range(len(outside) - 1):
+                    if not split_outside(k):
+                        continue
+                    f, z = outside[first], outside[k]
+                    lir = by[z[0]][z[1]][2]
+                    l = max((f[2] if not by[f[0]][f[1]][3] >= gain else by[f[0]][f[1]][1]) - D, by[f[0]][0][1])
+                    r = min((z[2] if not by[z[0]][z[1]][3] >= gain else lir) + D, by[z[0]][-1][2])
+                    if f[2] - half > l:
+                        l = f[2] - half
+                    if z[2] + half < r:
+                        r = z[2] + half
+                    if not self.pos2cni(f[0], l):
+                        l = by[f[0]][f[1]][1]
+                    if not self.pos2cni(z[0], r):
+                        r = lir
+                    refined.append([f[0], l, r, -1])
+                    refined_bps.append([])
+                    first = k + 1
+                if outside:
+                    f, z = outside[first], outside[-1]
+                    l = max((f[2] if not by[f[0]][f[1]][3] >= gain else by[f[0]][f[1]][1]) - D, by[f[0]][0][1])
+                    r = min((z[2] if not by[z[0]][z[1]][3] >= gain else by[z[0]][z[1]][2]) + D, by[z[0]][-1][2])
+                    if f[2] - half > l:
+                        l = f[2] - half
+                    if z[2] + half < r:
+                        r = z[2] + half
+                    if not self.pos2cni(f[0], l):
+                        l = by[f[0]][f[1]][1]
+                    if not self.pos2cni(f[0], r):
+                        r = by[f[0]][z[1]][2]
+                    refined.append([f[0], l, r, -1])
+                    refined_bps.append([])
 
             if set_handle:
                 _lib.lib().coral_pyset_batch_free(set_handle)

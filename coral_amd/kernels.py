@@ -186,28 +186,33 @@ def point_cover(dr, points: Sequence[Tuple[int, int]], pair_cap: int = 1 << 20, 
     return [per_uniq[j] for j in inverse.reshape(-1)]
 
 
-def _bp_candidates_local(dr, T, sel, mode: int, intervals, chr_rank, cutoff: int, min_mapq: int, gap_: int, gap_mapq: int) -> np.ndarray:
+def _bp_candidates_local(dr, T, sel, mode: int, intervals, chr_rank, cutoff: int, min_mapq: int, gap_: int, gap_mapq: int,
+                         groups=None):
     """int32 [K, 13] candidate rows from coral_bp_candidates (runs on this process's GPU; the chimeric table is small and
-    lives with the host logic, so this step is not sharded)."""
+    lives with the host logic, so this step is not sharded).  Mode 2 (``groups`` = interval index per selected read)
+    additionally returns the exclusive prefix of the per-read candidate counts (int32 [n_sel + 1])."""
     from .chimeric import ChimericTable  # noqa: F401
     L = _lib.lib()
     dev = dr.device
     n_sel = T.n_reads if sel is None else len(sel)
     if n_sel == 0 or T.n_rows == 0:
-        return np.zeros((0, 13), dtype=np.int32)
+        empty = np.zeros((0, 13), dtype=np.int32)
+        return (empty, np.zeros(n_sel + 1, dtype=np.int32)) if mode == 2 else empty
     off, qs, qe, tid, ra, rb, strand, mapq = T.device_arrays(dev)
     ct = _lib.coral_chimeric_t(T.n_reads, off.data_ptr(), qs.data_ptr(), qe.data_ptr(), tid.data_ptr(), ra.data_ptr(),
                                rb.data_ptr(), strand.data_ptr(), mapq.data_ptr())
-    # one upload for all small inputs: [selection | interval tid | start | end | chromosome ranks]
+    # one upload for all small inputs: [selection (| interval index per read) | interval tid | start | end | chromosome ranks]
     iv = np.asarray(intervals, dtype=np.int32).reshape(-1, 3)
     parts = [] if sel is None else [np.asarray(sel, dtype=np.int32)]
+    if mode == 2:
+        parts.append(np.asarray(groups, dtype=np.int32))
     parts += [iv[:, 0], iv[:, 1], iv[:, 2], np.asarray(chr_rank, dtype=np.int32)]
     packed = torch.from_numpy(np.concatenate(parts)).to(dev)
     at = packed.data_ptr()
     sel_ptr = None
     if sel is not None:
         sel_ptr = at
-        at += 4 * n_sel
+        at += 4 * n_sel * (2 if mode == 2 else 1)
     it_ptr, is_ptr, ie_ptr, cr_ptr = at, at + 4 * len(iv), at + 8 * len(iv), at + 12 * len(iv)
     counts = torch.empty(n_sel + 2, dtype=torch.int32, device=dev)
     cap = max(1024, 2 * n_sel)
@@ -223,7 +228,10 @@ def _bp_candidates_local(dr, T, sel, mode: int, intervals, chr_rank, cutoff: int
         if rc == -4:                      # CORAL_ERR_FORMAT: contig outside chr1..22,X,Y,M
             raise KeyError("contig name outside chr1..22,X,Y,M")      # gn:13-18 lookup at bu:293
         _lib.check(rc, "coral_bp_candidates")
-        return cand[:n_out.value].cpu().numpy()
+        rows = cand[:n_out.value].cpu().numpy()
+        if mode == 2:
+            return rows, counts[:n_sel + 1].cpu().numpy()
+        return rows
 
 
 def bp_candidates(dr, T, sel, mode: int, intervals, chr_rank, cutoff=100, min_mapq=20, gap_=100, gap_mapq=10):
@@ -231,6 +239,30 @@ def bp_candidates(dr, T, sel, mode: int, intervals, chr_rank, cutoff=100, min_ma
     from .chimeric import Candidates
     rows = _bp_candidates_local(dr, T, sel, mode, intervals, chr_rank, cutoff, min_mapq, gap_, gap_mapq).astype(np.int64)
     return Candidates(**{k: rows[:, j] for j, k in enumerate(Candidates.FIELDS)})
+
+
+def bp_candidates_grouped(dr, T, reads_per_query, first_intervals, second_interval, chr_rank, cutoff=100, min_mapq=20, gap_mapq=10):
+    """Several alignment2bp queries (bu:70-96) that share their second interval, in ONE coral_bp_candidates launch (mode 2).
+
+    ``reads_per_query[g]``: reads (indices into T, iteration order) of query g; ``first_intervals[g]`` its (tid, start, end).
+    Returns one ``Candidates`` per query, rows in the reference's order."""
+    from .chimeric import Candidates
+    if not reads_per_query:
+        return []
+    sizes = [len(r) for r in reads_per_query]
+    sel = np.concatenate([np.asarray(r, dtype=np.int32) for r in reads_per_query]) if sum(sizes) else np.zeros(0, dtype=np.int32)
+    groups = np.repeat(np.arange(len(sizes), dtype=np.int32), sizes)
+    rows, prefix = _bp_candidates_local(dr, T, sel, 2, list(first_intervals) + [second_interval], chr_rank, cutoff, min_mapq, 100,
+                                        gap_mapq, groups=groups)
+    rows = rows.astype(np.int64)
+    bounds = np.concatenate([[0], np.cumsum(sizes)])
+    out = []
+    for g in range(len(sizes)):
+        a = int(prefix[bounds[g]]) if bounds[g] < len(prefix) else len(rows)
+        b = int(prefix[bounds[g + 1]]) if bounds[g + 1] < len(prefix) else len(rows)
+        part = rows[a:b]
+        out.append(Candidates(**{k: part[:, j] for j, k in enumerate(Candidates.FIELDS)}))
+    return out
 
 
 def _sa_table_local(dr):

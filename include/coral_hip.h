@@ -137,6 +137,10 @@ const char *coral_sa_last_error(void);
  * -> breakpoint_utilities.py:70-96; mode 1, exactly two intervals I1, I2), including interval2bp
  * (breakpoint_utilities.py:289-295).  The chimeric table is a device SoA: rows of read r are off[r]..off[r+1], in the
  * reference's (qs, qe)-sorted order; ra/rb are rint[1]/rint[2] (ra > rb on '-' rows); strand 0 '+', 1 '-'.
+ * Mode 2 batches several mode-1 queries that share their second interval (all target intervals of one step of the
+ * interval search, ibg:405-434): `sel` then holds 2 * n_sel ints — the reads, then for every read the index of ITS first
+ * interval — and every read is paired with the LAST of the n_int intervals; after the call counts[0..n_sel] (device) is
+ * the exclusive prefix of the per-read candidate counts, i.e. where each read's (and so each query's) rows start.
  * `sel` lists the reads to process in iteration order (NULL = all reads).  Output rows are 13 int32:
  * c1, p1, o1, c2, p2, o2, read, i, j, query gap, swapped flag, mapq of the first, mapq of the second segment — in the
  * reference's order (reads as listed; per read consecutive-pair candidates, then skip-one candidates).

@@ -177,26 +177,31 @@ def install_cpu_kernel_fakes(monkeypatch):
             keys += [(j << 32) | (int(i) - dr.lo) for i in h.region(h.chroms[t], p, p + 1) if dr.lo <= i < dr.hi]
         return torch.tensor(keys, dtype=torch.int64)
 
-    def bp_candidates_local(dr, T, sel, mode, intervals, chr_rank, cutoff, min_mapq, gap_, gap_mapq):
-        """coral_bp_candidates stand-in: the oracle's alignment2bp / alignment2bp_l, read by read."""
+    def bp_candidates_local(dr, T, sel, mode, intervals, chr_rank, cutoff, min_mapq, gap_, gap_mapq, groups=None):
+        """coral_bp_candidates stand-in: the oracle's alignment2bp / alignment2bp_l, read by read (mode 2 = one alignment2bp
+        query per selected read's interval index against the last interval; also returns the per-read row prefix)."""
         from oracle import coral_oracle as O
         chroms = dr.header_chroms
         ori = {"+": 0, "-": 1}
         tid_of = {c: k for k, c in enumerate(chroms)}
-        rows = []
-        for r in (range(T.n_reads) if sel is None else sel):
+        rows, prefix = [], [0]
+        ivs = [[chroms[t], s, e] for t, s, e in intervals]
+        for k_sel, r in enumerate(range(T.n_reads) if sel is None else sel):
             a, b = int(T.off[r]), int(T.off[r + 1])
             ca = ([[int(T.qs[k]), int(T.qe[k])] for k in range(a, b)],
                   [[chroms[T.tid[k]], int(T.ra[k]), int(T.rb[k]), "+-"[T.strand[k]]] for k in range(a, b)],
                   [int(T.mapq[k]) for k in range(a, b)])
-            ivs = [[chroms[t], s, e] for t, s, e in intervals]
             if mode == 1:
                 out = O.alignment2bp(int(r), ca, cutoff, min_mapq, ivs[0], ivs[1], gap_mapq)
+            elif mode == 2:
+                out = O.alignment2bp(int(r), ca, cutoff, min_mapq, ivs[int(groups[k_sel])], ivs[-1], gap_mapq)
             else:
                 out = O.alignment2bp_l(int(r), ca, cutoff, min_mapq, gap_, ivs, gap_mapq)
             for c in out:
                 rows.append([tid_of[c[0]], c[1], ori[c[2]], tid_of[c[3]], c[4], ori[c[5]], c[6][0], c[6][1], c[6][2], c[7], c[8], c[9], c[10]])
-        return np.array(rows, dtype=np.int32).reshape(-1, 13)
+            prefix.append(len(rows))
+        rows = np.array(rows, dtype=np.int32).reshape(-1, 13)
+        return (rows, np.array(prefix, dtype=np.int32)) if mode == 2 else rows
 
     def sa_table_local(dr):
         """coral_sa_table stand-in: the oracle's fetch() (string SA entries, per-read Python lists) turned into arrays."""

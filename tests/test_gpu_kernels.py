@@ -307,3 +307,30 @@ def test_sa_table_error_semantics():
         dict(tid=0, pos=20, cigar=[(M, 50)], name="y")])
     with pytest.raises(ZeroDivisionError):
         build_chimeric_table(DeviceRecords(zero, "cuda:0"))
+
+
+def test_bp_candidates_grouped_equals_single_queries():
+    """Mode 2 of coral_bp_candidates (all target runs of one step of the interval search in ONE launch) returns, query by
+    query, exactly the rows of separate mode-1 launches — including empty queries and reads listed in several queries."""
+    from coral_amd import kernels
+    from coral_amd.chimeric import build_chimeric_table, Candidates
+    from coral_amd.records import DeviceRecords
+    from coral_amd.global_names import chr_idx
+    cfg, rec = synth.dataset("ultra", "cpu")
+    dr = DeviceRecords(rec, "cuda:0")
+    T = build_chimeric_table(dr)
+    chr_rank = np.array([chr_idx.get(c, -1) for c in dr.header_chroms], dtype=np.int64)
+    rng = np.random.default_rng(3)
+    segs = [(sg.tid, sg.start, sg.end) for circle in cfg.circles for sg in circle]
+    here = segs[0]
+    queries, targets = [], []
+    for g in range(9):
+        n = int(rng.choice([0, 1, 40, 250]))
+        queries.append(rng.integers(0, T.n_reads, n))
+        targets.append(segs[1 + g % (len(segs) - 1)])
+    got = kernels.bp_candidates_grouped(dr, T, queries, targets, here, chr_rank)
+    assert len(got) == len(queries) and sum(len(c) for c in got) > 20
+    for reads, tgt, c in zip(queries, targets, got):
+        want = kernels.bp_candidates(dr, T, reads, 1, [tgt, here], chr_rank)
+        for f in Candidates.FIELDS:
+            assert np.array_equal(getattr(c, f), getattr(want, f)), f
