@@ -32,6 +32,7 @@ import numpy as np
 import ctypes as C
 import os
 import weakref
+from concurrent.futures import ThreadPoolExecutor
 
 from . import _lib, global_names, kernels
 from .bpcluster import call_breakpoints, bpc2bp, cluster_bp_list
@@ -210,6 +211,7 @@ class bam_to_breakpoint_nanopore():
         self.normal_cov = 0.0
         self.ccid2id = dict()
         self.new_bp_list = []
+        self._pool, self._ahead = None, {}           # look-ahead of the interval search (find_amplicon_intervals)
         self._bp_name_ids: Dict[int, list] = {}     # id(support set) -> [name id arrays]; see addbp
         self.new_bp_stats = []
         self.new_bp_ccids = []
@@ -407,10 +409,24 @@ class bam_to_breakpoint_nanopore():
             if self.pos2cni(c, by[c][rcni][2] + self.interval_delta):
                 iv[2] = by[c][rcni][2] + self.interval_delta
         ccid = 0
-        for ai in range(len(self.amplicon_intervals)):
-            if self.amplicon_intervals[ai][3] == -1:
-                self.find_interval_i(ai, ccid)
-                ccid += 1
+        # look-ahead worker for the pure part of every search step (_prepare_step); results are keyed by interval index and
+        # coordinates, so a step is recomputed in line if its interval changed after it was queued (it never does today)
+        self._ahead = {}
+        self._pool = None if _VERIFY_SET_ORDER else ThreadPoolExecutor(max_workers=1, thread_name_prefix="coral-ahead")
+        try:
+            if self._pool is not None and len(self._chim.read):
+                self._read_hashes()                                    # shared caches are filled before the worker starts
+                self._chim.device_arrays(self.rec.device)
+                for ai in range(len(self.amplicon_intervals)):
+                    self._submit_ahead(ai)
+            for ai in range(len(self.amplicon_intervals)):
+                if self.amplicon_intervals[ai][3] == -1:
+                    self.find_interval_i(ai, ccid)
+                    ccid += 1
+        finally:
+            if self._pool is not None:
+                self._pool.shutdown(wait=True, cancel_futures=True)
+            self._pool, self._ahead = None, {}
         logging.debug(_t() + "Identified %d amplicon intervals in total." % len(self.amplicon_intervals))
         self._merge_intervals()
 
@@ -623,13 +639,11 @@ class bam_to_breakpoint_nanopore():
             T._hashes = np.ascontiguousarray(hv[ids])
         return T._hashes
 
-    def _iteration_order(self, handle, key_ids) -> np.ndarray:
-        """Read indices in the order ``for r in (set() | sets[k0] | sets[k1] | ...)`` would visit them (ibg:405-432)."""
+    def _iteration_order(self, handle, key_ids, out) -> np.ndarray:
+        """Read indices in the order ``for r in (set() | sets[k0] | sets[k1] | ...)`` would visit them (ibg:405-432).
+        ``out``: int32 scratch of n_reads + 1 entries (owned by the calling thread)."""
         L = _lib.lib()
         k = np.ascontiguousarray(np.asarray(key_ids, dtype=np.int32))
-        out = getattr(self._chim, "_order_buf", None)
-        if out is None:
-            out = self._chim._order_buf = np.empty(self._chim.n_reads + 1, dtype=np.int32)
         n = C.c_int32(0)
         _lib.check(L.coral_pyset_union_order(handle, len(k), k.ctypes.data, out.ctypes.data, C.byref(n)), "coral_pyset_union_order")
         order = out[:n.value].astype(np.int64)
@@ -642,6 +656,62 @@ class bam_to_breakpoint_nanopore():
             assert [self.chimeric_alignments._index[nm] for nm in acc] == order.tolist(), "set-order replay diverged from CPython"
         return order
 
+    def _prepare_step(self, chrom, s, e):
+        """The part of one step of the interval search that is a pure function of the interval's coordinates (ibg:362-434):
+        reachable segments and their read sets, the runs of neighbouring segments, the iteration order of every run's reads
+        and the breakpoint candidates between each run and the interval (one coral_bp_candidates launch).  Being pure, it is
+        computed AHEAD of the search on a worker thread as soon as an interval enters the queue (the native calls release the
+        interpreter lock), while the main thread does the order-dependent work of the previous step.
+        Returns ("ok", None | (plan, candidates per run)) or ("error", exception to raise where the reference raises)."""
+        try:
+            by = self.cns_intervals_by_chr
+            T = self._chim
+            try:
+                si = self.pos2cni(chrom, s)[0]
+                ei = self.pos2cni(chrom, e)[0]
+            except Exception:
+                return "ok", None
+            reach, counts, set_handle = self._reachable_segments(chrom, si, ei)
+            try:
+                for c in list(reach):
+                    for j in [j for j in reach[c] if counts[reach[c][j]] < self.min_cluster_cutoff]:
+                        del reach[c][j]
+                    if not reach[c]:
+                        del reach[c]
+                # every (chromosome, run of neighbouring segments) reached from this interval, in the reference's order
+                plan = []
+                for c in reach:
+                    bins = sorted(reach[c])
+                    members, first = [], 0                  # members: key ids whose sets the reference unions with |=
+                    for k in range(len(bins) - 1):
+                        members.append(reach[c][bins[k]])
+                        if bins[k + 1] - bins[k] > 2 or by[c][bins[k + 1]][1] - by[c][bins[k]][2] > self.max_seq_len:
+                            plan.append((c, bins[first], bins[k], members))
+                            first = k + 1
+                            members = []
+                    members.append(reach[c][bins[-1]])
+                    plan.append((c, bins[first], bins[-1], members))
+                buf = np.empty(T.n_reads + 1, dtype=np.int32)
+                orders = [self._iteration_order(set_handle, keys, buf) for (_, _, _, keys) in plan]   # set-of-str order (Q21)
+            finally:
+                if set_handle:
+                    _lib.lib().coral_pyset_batch_free(set_handle)
+            targets = [(self._tid_of[c], by[c][b0][1], by[c][b1][2]) for (c, b0, b1, _) in plan]
+            all_cands = kernels.bp_candidates_grouped(self.rec, T, orders, targets, (self._tid_of[chrom], s, e), self._chr_rank,
+                                                      self.min_bp_match_cutoff_, 20) if plan else []
+            for cands in all_cands:
+                cands.read = T.name_id[cands.read]
+            return "ok", (plan, all_cands)
+        except Exception as exc:                        # noqa: BLE001 — raised by the caller at the reference's point
+            return "error", exc
+
+    def _submit_ahead(self, idx):
+        if self._pool is not None:
+            coords = tuple(self.amplicon_intervals[idx][:3])
+            old = self._ahead.get(idx)
+            if old is None or old[0] != coords:
+                self._ahead[idx] = (coords, self._pool.submit(self._prepare_step, *coords))
+
     def find_interval_i(self, ai, ccid):
         """Breadth-first search for intervals connected to interval ``ai`` by breakpoint edges (ibg:343-673)."""
         by = self.cns_intervals_by_chr
@@ -649,48 +719,30 @@ class bam_to_breakpoint_nanopore():
         D = self.interval_delta
         T = self._chim
         queue = [ai]
+        ahead = self._ahead                     # interval index -> (coordinates, future of _prepare_step); see find_amplicon_intervals
+        self._submit_ahead(ai)
         while queue:
             cur = queue.pop(0)
             chrom, s, e = self.amplicon_intervals[cur][:3]
             if self.amplicon_intervals[cur][3] == -1:
                 self.amplicon_intervals[cur][3] = ccid
             logging.debug(_t() + "\t\tNext amplicon interval %d: %s." % (cur, self.amplicon_intervals[cur]))
-            try:
-                si = self.pos2cni(chrom, s)[0]
-                ei = self.pos2cni(chrom, e)[0]
-            except Exception:
+            entry = ahead.get(cur)
+            if entry is not None and entry[0] == (chrom, s, e):
+                status, prepared = entry[1].result()
+            else:
+                status, prepared = self._prepare_step(chrom, s, e)
+            if status == "error":
+                raise prepared
+            if prepared is None:
                 continue
-            reach, counts, set_handle = self._reachable_segments(chrom, si, ei)
-            for c in list(reach):
-                for j in [j for j in reach[c] if counts[reach[c][j]] < self.min_cluster_cutoff]:
-                    del reach[c][j]
-                if not reach[c]:
-                    del reach[c]
-            refined, refined_bps = [], []
-            # every (chromosome, run of neighbouring segments) reached from this interval, in the reference's order
+            plan, all_cands = prepared
             here = self.amplicon_intervals[cur]            # not modified before all groups are done (ibg:385-612)
-            plan = []
-            for c in reach:
-                bins = sorted(reach[c])
-                members, first = [], 0                      # members: key ids whose sets the reference unions with |=
-                for k in range(len(bins) - 1):
-                    members.append(reach[c][bins[k]])
-                    if bins[k + 1] - bins[k] > 2 or by[c][bins[k + 1]][1] - by[c][bins[k]][2] > self.max_seq_len:
-                        plan.append((c, bins[first], bins[k], members))
-                        first = k + 1
-                        members = []
-                members.append(reach[c][bins[-1]])
-                plan.append((c, bins[first], bins[-1], members))
-            # candidates of ALL groups in one launch: alignment2bp between each target run and the current interval
-            orders = [self._iteration_order(set_handle, keys) for (_, _, _, keys) in plan]     # set-of-str iteration order (Q21)
-            targets = [(self._tid_of[c], by[c][b0][1], by[c][b1][2]) for (c, b0, b1, _) in plan]
-            all_cands = kernels.bp_candidates_grouped(self.rec, T, orders, targets, (self._tid_of[here[0]], here[1], here[2]),
-                                                      self._chr_rank, self.min_bp_match_cutoff_, 20) if plan else []
+            refined, refined_bps = [], []
             for gi, (c, b0, b1, _) in enumerate(plan):
                 ns, ne = by[c][b0][1], by[c][b1][2]
                 tgt = [c, ns, ne]
                 cands = all_cands[gi]
-                cands.read = T.name_id[cands.read]
                 logging.debug(_t() + "\t\tFound %d reads connecting the two intervals." % len(cands))
                 found = []
                 for bp, tuples, st, ids in self._call_breakpoints(cands, advance_subcluster=False):
@@ -811,8 +863,6 @@ class bam_to_breakpoint_nanopore():
                     refined.append([f[0], l, r, -1])
                     refined_bps.append([])
 
-            if set_handle:
-                _lib.lib().coral_pyset_batch_free(set_handle)
             conn = self.amplicon_interval_connections
             for ni, cand_iv in enumerate(refined):
                 hit, parts = interval_exclusive(cand_iv, self.amplicon_intervals)
@@ -826,6 +876,7 @@ class bam_to_breakpoint_nanopore():
                     for o in hit:
                         if o != cur and self.amplicon_intervals[o][3] < 0:
                             queue.append(o)
+                            self._submit_ahead(o)
                 else:
                     for part in parts:
                         nai = len(self.amplicon_intervals)
@@ -844,6 +895,7 @@ class bam_to_breakpoint_nanopore():
                                 else:
                                     conn[(cur, nai)].add(k)
                         queue.append(nai)
+                        self._submit_ahead(nai)
 
     def _add_clustered(self, cands: Candidates):
         """Tail shared by find_breakpoints and find_smalldel_breakpoints (ibg:691-718, ibg:775-802)."""
