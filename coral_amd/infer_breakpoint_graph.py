@@ -533,16 +533,21 @@ class bam_to_breakpoint_nanopore():
     def _read_tuples(self, c: Candidates, idx):
         return list(zip(self._names_of(c.read[idx]), c.i[idx].tolist(), c.j[idx].tolist()))
 
-    def _call_breakpoints(self, c: Candidates, advance_subcluster: bool):
-        """Cluster the candidates and yield (bp list, support tuples, stats) for every accepted (sub)cluster.
+    def _cluster_and_call(self, c: Candidates, advance_subcluster: bool):
+        """Native part of _call_breakpoints: (cluster sizes, accepted calls) — a pure function of the candidates."""
+        floor = max(self.normal_cov * self.min_bp_cov_factor, 3.0)
+        return call_breakpoints(c, self.min_cluster_cutoff, self.max_breakpoint_distance_cutoff, self.min_bp_match_cutoff_, floor,
+                                advance_subcluster)
+
+    def _call_breakpoints(self, c: Candidates, advance_subcluster: bool, called=None):
+        """Cluster the candidates and yield (bp list, support tuples, stats, name ids) for every accepted (sub)cluster.
 
         ``advance_subcluster`` is False inside the interval BFS, where the reference never increments its
         sub-cluster counter (ibg:442-457, Appendix A Q4), and True in find_breakpoints / find_smalldel_breakpoints.
+        ``called``: the result of ``_cluster_and_call`` when it was computed ahead.
         """
         chroms = self.rec.header_chroms
-        floor = max(self.normal_cov * self.min_bp_cov_factor, 3.0)
-        sizes, calls = call_breakpoints(c, self.min_cluster_cutoff, self.max_breakpoint_distance_cutoff,
-                                        self.min_bp_match_cutoff_, floor, advance_subcluster)
+        sizes, calls = called if called is not None else self._cluster_and_call(c, advance_subcluster)
         if logging.getLogger().isEnabledFor(logging.DEBUG):
             for sz in sizes:
                 logging.debug(_t() + "New cluster of size %d." % sz)
@@ -658,11 +663,13 @@ class bam_to_breakpoint_nanopore():
 
     def _prepare_step(self, chrom, s, e):
         """The part of one step of the interval search that is a pure function of the interval's coordinates (ibg:362-434):
-        reachable segments and their read sets, the runs of neighbouring segments, the iteration order of every run's reads
-        and the breakpoint candidates between each run and the interval (one coral_bp_candidates launch).  Being pure, it is
+        reachable segments and their read sets, the runs of neighbouring segments, the iteration order of every run's reads,
+        the breakpoint candidates between each run and the interval (one coral_bp_candidates launch) and their clustering
+        into exact breakpoints (coral_call_breakpoints).  Being pure, it is
         computed AHEAD of the search on a worker thread as soon as an interval enters the queue (the native calls release the
         interpreter lock), while the main thread does the order-dependent work of the previous step.
-        Returns ("ok", None | (plan, candidates per run)) or ("error", exception to raise where the reference raises)."""
+        Returns ("ok", None | (plan, candidates per run, calls per run)) or ("error", exception to raise where the reference
+        raises)."""
         try:
             by = self.cns_intervals_by_chr
             T = self._chim
@@ -699,9 +706,11 @@ class bam_to_breakpoint_nanopore():
             targets = [(self._tid_of[c], by[c][b0][1], by[c][b1][2]) for (c, b0, b1, _) in plan]
             all_cands = kernels.bp_candidates_grouped(self.rec, T, orders, targets, (self._tid_of[chrom], s, e), self._chr_rank,
                                                       self.min_bp_match_cutoff_, 20) if plan else []
+            called = []
             for cands in all_cands:
                 cands.read = T.name_id[cands.read]
-            return "ok", (plan, all_cands)
+                called.append(self._cluster_and_call(cands, False))
+            return "ok", (plan, all_cands, called)
         except Exception as exc:                        # noqa: BLE001 — raised by the caller at the reference's point
             return "error", exc
 
@@ -736,7 +745,7 @@ class bam_to_breakpoint_nanopore():
                 raise prepared
             if prepared is None:
                 continue
-            plan, all_cands = prepared
+            plan, all_cands, called = prepared
             here = self.amplicon_intervals[cur]            # not modified before all groups are done (ibg:385-612)
             refined, refined_bps = [], []
             for gi, (c, b0, b1, _) in enumerate(plan):
@@ -745,7 +754,7 @@ class bam_to_breakpoint_nanopore():
                 cands = all_cands[gi]
                 logging.debug(_t() + "\t\tFound %d reads connecting the two intervals." % len(cands))
                 found = []
-                for bp, tuples, st, ids in self._call_breakpoints(cands, advance_subcluster=False):
+                for bp, tuples, st, ids in self._call_breakpoints(cands, advance_subcluster=False, called=called[gi]):
                     k = self.addbp(bp, set(tuples), st, ccid, ids)
                     if k not in found:
                         found.append(k)
