@@ -412,7 +412,7 @@ class bam_to_breakpoint_nanopore():
         # look-ahead worker for the pure part of every search step (_prepare_step); results are keyed by interval index and
         # coordinates, so a step is recomputed in line if its interval changed after it was queued (it never does today)
         self._ahead = {}
-        self._pool = None if _VERIFY_SET_ORDER else ThreadPoolExecutor(max_workers=1, thread_name_prefix="coral-ahead")
+        self._pool = None if _VERIFY_SET_ORDER else ThreadPoolExecutor(max_workers=int(os.environ.get("CORAL_AHEAD_THREADS", "2")), thread_name_prefix="coral-ahead")
         try:
             if self._pool is not None and len(self._chim.read):
                 self._read_hashes()                                    # shared caches are filled before the worker starts
