@@ -136,16 +136,23 @@ def cn_problem(g, normal_cov):
 
 
 def _independent_rows(A, tol=1e-9):
-    """Indices of a maximal linearly independent subset of the rows of A (entries are 0 / ±1), by modified
-    Gram-Schmidt.  Redundant balance rows are consistent (right-hand side 0), so dropping them changes nothing."""
-    keep, basis = [], []
-    for k in range(A.shape[0]):
-        v = A[k].astype(np.float64).copy()
-        for b in basis:
-            v -= (v @ b) * b
-        nv = np.linalg.norm(v)
-        if nv > tol * max(1.0, np.linalg.norm(A[k])):
-            basis.append(v / nv)
+    """Indices of a maximal linearly independent subset of the rows of A (entries are 0 / ±1): row k is kept when it is not
+    in the span of the rows kept before it (Gram-Schmidt against the orthonormal basis so far, applied twice for stability).
+    Redundant balance rows are consistent (right-hand side 0), so dropping them changes nothing."""
+    m, n = A.shape
+    Af = A.astype(np.float64)
+    norms = np.maximum(1.0, np.linalg.norm(Af, axis=1))
+    B = np.zeros((m, n))
+    keep = []
+    for k in range(m):
+        v = Af[k].copy()
+        if keep:
+            Q = B[:len(keep)]
+            v -= Q.T @ (Q @ v)
+            v -= Q.T @ (Q @ v)
+        nv = float(np.sqrt(v @ v))
+        if nv > tol * norms[k]:
+            B[len(keep)] = v / nv
             keep.append(k)
     return keep
 
