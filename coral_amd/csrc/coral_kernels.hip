@@ -207,7 +207,7 @@ __device__ __forceinline__ int wave_sum_dpp(int x) {
 // only around actual large deletions and at the (padded) end of a record.
 // TILE > 1: a wave takes TILE consecutive records at a time (tiles interleaved over the waves) instead of every
 // nwaves-th record, so its loads and its scalar metadata reads walk contiguous memory.
-template <int BATCH, bool LIGHT = false, bool FILTER = false, int TILE = 1>
+template <int BATCH, bool LIGHT = false, bool FILTER = false, int TILE = 1, bool FULLCHUNK = false>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
     long long n_rec, const int32_t *__restrict__ pos, const int32_t *__restrict__ flagmq,
     const int32_t *__restrict__ n_cigar, const int64_t *__restrict__ cigar_off,
@@ -249,8 +249,13 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
     auto f_fetch = [&](cquad_t (&dst)[BATCH]) {
 #pragma unroll
         for (int j = 0; j < BATCH; ++j) {
-            dst[j] = pad;
-            if (fc + j * WAVE + lane < fnq) dst[j] = fq[fc + j * WAVE + lane];     // exec-masked dwordx4
+            if (FULLCHUNK && fc + (j + 1) * WAVE <= fnq) {          // (wave-uniform) whole chunk inside the record:
+                const cquad_t *__restrict__ base = fq + fc + j * WAVE;      // SGPR base + lane offset, no masking, no padding fill
+                dst[j] = base[lane];
+            } else {
+                dst[j] = pad;
+                if (fc + j * WAVE + lane < fnq) dst[j] = fq[fc + j * WAVE + lane];     // exec-masked dwordx4
+            }
         }
     };
     auto f_step = [&]() {
@@ -1288,7 +1293,7 @@ extern "C" int coral_time_stream_read(const uint32_t *cigar, long long n_words, 
 
 static int g_scan_variant = 15;  // 8 KiB per wave in flight + conservative gap filter + tiles of 8 consecutive records per wave: best launch time (profiles/r01_scan_variants.md)
 extern "C" int coral_set_scan_variant(int v) {
-    if (v < 1 || v > 22) return CORAL_ERR_ARG;
+    if (v < 1 || v > 24) return CORAL_ERR_ARG;
     g_scan_variant = v;
     return CORAL_OK;
 }
@@ -1384,6 +1389,14 @@ extern "C" int coral_cigar_scan(const coral_records_t *rec, int32_t min_gap, int
         LAUNCH_TILE(8, 16);
     else if (g_scan_variant == 22)
         LAUNCH_TILE(4, 8);
+    else if (g_scan_variant == 23)
+        hipLaunchKernelGGL((k_cigar_scan_v2<8, false, true, 8, true>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
+                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
+                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
+    else if (g_scan_variant == 24)
+        hipLaunchKernelGGL((k_cigar_scan_v2<4, true, true, 8, true>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
+                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
+                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
     else if (g_scan_variant == 17)
         LAUNCH_TILED(8, false, 4);
     else if (g_scan_variant == 18)
