@@ -412,7 +412,9 @@ class bam_to_breakpoint_nanopore():
         # look-ahead worker for the pure part of every search step (_prepare_step); results are keyed by interval index and
         # coordinates, so a step is recomputed in line if its interval changed after it was queued (it never does today)
         self._ahead = {}
-        self._pool = None if _VERIFY_SET_ORDER else ThreadPoolExecutor(max_workers=int(os.environ.get("CORAL_AHEAD_THREADS", "2")), thread_name_prefix="coral-ahead")
+        self._pool = None if _VERIFY_SET_ORDER else ThreadPoolExecutor(
+            max_workers=int(os.environ.get("CORAL_AHEAD_THREADS", "2")), thread_name_prefix="coral-ahead",
+            initializer=_bind_thread_to_device, initargs=(self.rec.device,))
         try:
             if self._pool is not None and len(self._chim.read):
                 self._read_hashes()                                    # shared caches are filled before the worker starts
@@ -1322,6 +1324,15 @@ class _SegIndexView:
 
 
 PHASE_SECONDS: Dict[str, float] = {}      # wall time of every phase of the last build (same phases the reference logs)
+
+
+def _bind_thread_to_device(device):
+    """The current GPU is a per-thread setting of the HIP runtime: worker threads must select the records' device before
+    they launch kernels on its streams."""
+    import torch
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)
 
 
 def build_graph_from_records(records, seedfile, cn_seg, output_prefix=None, min_bp_support=1.0, output_bp=False,

@@ -26,6 +26,8 @@ class DeviceRecords:
         by CIGAR-op count); the small host mirrors always describe the whole file."""
         self.device = torch.device(device)
         dev = self.device
+        if dev.type == "cuda":
+            torch.cuda.set_device(dev)          # libcoral_hip launches on this device's streams: it must be the thread's current GPU
         self.rank, self.world, self.group = int(rank), int(world), group
         self.n_total = int(rec.n)
         self.header_chroms = list(rec.header_chroms)
