@@ -35,6 +35,7 @@ import weakref
 from concurrent.futures import ThreadPoolExecutor
 
 from . import _lib, global_names, kernels
+from . import _pyobjects          # CPython extension built by __graft_entry__.build(); no Python fallback
 from .bpcluster import call_breakpoints, bpc2bp, cluster_bp_list
 from .breakpoint_graph import (BreakpointGraph, breakpoint_info_text, compute_cn_lr, graph_text,
                                output_breakpoint_graph_lr, output_breakpoint_info_lr)
@@ -524,16 +525,13 @@ class bam_to_breakpoint_nanopore():
 
     # -- candidate clusters -> breakpoints ---------------------------------------------------------
     def _names_of(self, ids) -> list:
-        """Read-name strings of an array of name ids (C-level lookup)."""
-        ids = ids.tolist() if hasattr(ids, "tolist") else list(ids)
-        if not ids:
-            return []
-        if len(ids) == 1:
-            return [self.rec.names[ids[0]]]
-        return list(itemgetter(*ids)(self.rec.names))
+        """Read-name strings of an array of name ids (coral_amd._pyobjects: one C loop, no per-item interpreter work)."""
+        return _pyobjects.names_of(self.rec.names, np.ascontiguousarray(ids, dtype=np.int64))
 
     def _read_tuples(self, c: Candidates, idx):
-        return list(zip(self._names_of(c.read[idx]), c.i[idx].tolist(), c.j[idx].tolist()))
+        """[(name, i, j)] of the candidates ``idx`` — the support tuples of bu:81 / ibg:772."""
+        g = lambda a: np.ascontiguousarray(a[idx], dtype=np.int64)
+        return _pyobjects.read_tuples(self.rec.names, g(c.read), g(c.i), g(c.j))
 
     def _cluster_and_call(self, c: Candidates, advance_subcluster: bool):
         """Native part of _call_breakpoints: (cluster sizes, accepted calls) — a pure function of the candidates."""

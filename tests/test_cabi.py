@@ -88,3 +88,22 @@ def test_first_fit_equals_quadratic_definition():
         _lib.check(L.coral_cluster_first_fit(n, p1.ctypes.data, p2.ctypes.data, cut, out.ctypes.data, ctypes.byref(k)), "ff")
         exp = definition(p1.tolist(), p2.tolist(), cut)
         assert out.tolist() == exp and k.value == max(exp) + 1
+
+
+def test_pyobjects_extension_builds_the_reference_containers():
+    """coral_amd._pyobjects (CPython C API): same lists as the plain Python expressions, and loud errors."""
+    import numpy as np
+    import pytest
+    from coral_amd import _pyobjects as P
+    names = ["r%d" % k for k in range(50)]
+    ids = np.array([3, 3, 49, 0], dtype=np.int64)
+    i, j = np.array([0, 1, 2, 300], dtype=np.int64), np.array([1, 0, 5, -7], dtype=np.int64)
+    assert P.names_of(names, ids) == [names[k] for k in ids]
+    assert P.read_tuples(names, ids, i, j) == [(names[a], int(b), int(c)) for a, b, c in zip(ids, i, j)]
+    assert P.names_of(names, np.zeros(0, dtype=np.int64)) == []
+    with pytest.raises(IndexError):
+        P.names_of(names, np.array([50], dtype=np.int64))
+    with pytest.raises(TypeError):
+        P.read_tuples(names, ids.astype(np.int32), i, j)
+    with pytest.raises(ValueError):
+        P.read_tuples(names, ids, i[:2], j)
