@@ -95,3 +95,52 @@ def test_properties_at_scale():
     # (6) idempotence: a second scan gives identical results
     sc2 = kernels.cigar_scan(dr)
     assert torch.equal(sc.mbases, sc2.mbases) and np.array_equal(sc.gaps, sc2.gaps)
+
+
+def test_properties_at_full_size(tmp_path):
+    """BASELINE.json config 3 at FULL size (2 M reads x 20 kb, 3.99e9 CIGAR ops, 16 GB of CIGAR in HBM): size-independent
+    properties instead of the oracle (which needs ~5 min per 50 k reads)."""
+    import torch
+    from coral_amd import kernels, _lib, sharding
+    from coral_amd.records import DeviceRecords
+    cfg = synth.named_config("cfg3")
+    rec = synth.generate(cfg, "cuda:0", chunk_pieces=200000)
+    dr = DeviceRecords(rec, "cuda:0")
+    sc = kernels.cigar_scan(dr)
+    # (1) two differently structured kernels (default tiled + filtered vs the first batched one) agree on every output
+    assert _lib.lib().coral_set_scan_variant(3) == 0
+    try:
+        sc3 = kernels.cigar_scan(dr)
+    finally:
+        _lib.lib().coral_set_scan_variant(15)
+    for k in ("mbases", "qinfer", "blk_first", "blk_last"):
+        assert torch.equal(getattr(sc, k), getattr(sc3, k)), k
+    assert np.array_equal(sc.gaps, sc3.gaps) and len(sc.gaps) > 1000
+    # (2) partition invariance: the scan of two record shards, concatenated, is the scan of the whole (what sharding relies on)
+    parts = []
+    for r in range(2):
+        shard = DeviceRecords(rec, "cuda:0", rank=r, world=2)
+        mb, qi, b0, b1, rows = kernels._scan_local(shard, 600, 20, 1 << 16)
+        parts.append((shard.lo, shard.hi, mb, qi, b0, b1))
+        del shard
+    assert parts[0][0] == 0 and parts[0][1] == parts[1][0] and parts[1][1] == dr.n
+    assert torch.equal(torch.cat([p[2] for p in parts]), sc.mbases) and torch.equal(torch.cat([p[5] for p in parts]), sc.blk_last)
+    # (3) aligned bases of a whole contig == Σ per-record sums (checksum of checksums), reads counted once
+    mb = sc.mbases.cpu().numpy().astype(np.int64)
+    t = cfg.windows[1][0]
+    on = (dr.h_tid == t) & dr.h_has_seq
+    nr, nb = kernels.segment_coverage(dr, sc, [(t, 0, 1 << 30)])
+    assert nb[0] == int(mb[on].sum()) - int((dr.h_tid[dr.h_nonacgt_rec] == t).sum()) and nr[0] == int((dr.h_tid == t).sum())
+    # (4) the full build is deterministic: two runs give byte-identical graph files, every amplicon balanced
+    cn, seeds = str(tmp_path / "cn.bed"), str(tmp_path / "seeds.bed")
+    synth.write_cn_bed(cfg, cn); synth.write_seed_bed(cfg, seeds)
+    b1 = sharding.build_graph_sharded(dr, seeds, cn, str(tmp_path / "a"))
+    b2 = sharding.build_graph_sharded(dr, seeds, cn, str(tmp_path / "b"))
+    assert len(b1.lr_graph) >= 1 and len(b1.new_bp_list) == len(b2.new_bp_list) > 10
+    for k in range(len(b1.lr_graph)):
+        ta = open(str(tmp_path / ("a_amplicon%d_graph.txt" % (k + 1)))).read()
+        assert ta == open(str(tmp_path / ("b_amplicon%d_graph.txt" % (k + 1)))).read() and ta.count("discordant") > 5
+    # (5) every discordant edge's support equals its number of distinct (read, i, j) tuples and is at least the cluster cut-off
+    for g in b1.lr_graph:
+        for e in g.discordant_edges:
+            assert e[9] == len(e[10]) >= b1.min_cluster_cutoff
