@@ -168,13 +168,15 @@ __device__ __forceinline__ cquad_t pad_or(const cquad_t *__restrict__ q, long lo
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1 (variant 2)  same contract as k_cigar_scan, restructured for the memory system:
-//   * the (record, chunk) sequence of a wave is flattened and the loads run TWO chunks (2 KiB per wave)
-//     ahead of the arithmetic, across record boundaries, so a wave never idles on the dependent
-//     metadata -> first-quad load chain at the start of a record;
-//   * record metadata is wave-uniform and fetched with scalar loads (readfirstlane'd record ordinal);
+// K1  k_cigar_scan_v2 — the production scan kernel (default instantiation <8, false, true, 8>: 8 KiB per wave in flight,
+// conservative gap filter, tiles of 8 consecutive records per wave).  Same contract as k_cigar_scan above, restructured
+// for the memory system:
+//   * the (record, chunk) sequence of a wave is flattened and a whole batch of chunks is loaded ahead of the arithmetic,
+//     across record boundaries, so a wave never idles on the metadata -> first-quad load chain at the start of a record;
+//   * record metadata is wave-uniform and fetched with scalar loads, one record ahead of its use;
 //   * the wave scan / reductions use DPP row shifts + row broadcasts (6 VALU ops, no LDS crossbar), and
-//     wave-uniform values are taken with v_readlane instead of a shuffle.
+//     wave-uniform values are taken with v_readlane instead of a shuffle;
+//   * FILTER / TILE / FULLCHUNK: see the template below and profiles/r01_scan_variants.md.
 // ---------------------------------------------------------------------------------------------
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_zero(int src) {
@@ -441,801 +443,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// K1 (variant 6, "flat")  every wave owns a CONTIGUOUS RANGE OF WHOLE RECORDS holding ~1/n_waves of all ops and
-// streams that range as one flat run of 16-byte quads (the access pattern that reaches the plain-read rate), BATCH
-// KiB in flight ahead of the arithmetic.  Record boundaries are quad-aligned (the layout pads every record), so a
-// chunk that contains a boundary is simply processed once per record with the other record's lanes masked to
-// padding.  Same outputs as the other variants.
-// ---------------------------------------------------------------------------------------------
-struct RecState {
-    int carry_ref, carry_end, msum, qsum, first;
-};
-
-__device__ __forceinline__ void scan_chunk(const cquad_t b0, const int lane, RecState &st, const bool gaps_on, const int min_gap,
-                                           const int rec, const int quad_in_rec, const int p0, int32_t *__restrict__ gaps,
-                                           uint32_t *__restrict__ gap_count, const uint32_t gap_cap) {
-    const unsigned long long OPCLASS = 0x0000000770441147ull;
-    int len[4], adv[4], aend[4], ref[4];
-    bool aln[4];
-    int tot = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t w = b0[k];
-        const uint32_t f = (uint32_t)(OPCLASS >> ((w << 2) & 60u));
-        len[k] = (int)(w >> 4);
-        adv[k] = len[k] & -(int)(f & 1u);
-        const int alen = len[k] & -(int)((f >> 1) & 1u);
-        aln[k] = (f >> 1) & 1u;
-        aend[k] = alen;
-        st.msum += alen;
-        st.qsum += len[k] & -(int)((f >> 2) & 1u);
-        tot += adv[k];
-    }
-    const int incl = wave_incl_scan_add_dpp(tot);
-    ref[0] = st.carry_ref + incl - tot;
-    ref[1] = ref[0] + adv[0];
-    ref[2] = ref[1] + adv[1];
-    ref[3] = ref[2] + adv[2];
-    int run[4];
-    run[0] = aln[0] ? ref[0] + aend[0] : 0;
-    run[1] = aln[1] ? ref[1] + aend[1] : run[0];
-    run[2] = aln[2] ? ref[2] + aend[2] : run[1];
-    run[3] = aln[3] ? ref[3] + aend[3] : run[2];
-    int mx = run[3];
-    mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x111, 0xf, 0xf, true));
-    mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x112, 0xf, 0xf, true));
-    mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x114, 0xf, 0xf, true));
-    mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x118, 0xf, 0xf, true));
-    mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x142, 0xa, 0xf, true));
-    mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x143, 0xc, 0xf, true));
-    const int shifted = __builtin_amdgcn_update_dpp(st.carry_end, mx, 0x138, 0xf, 0xf, false);   // wave_shr:1
-    const int prev_in = max(shifted, st.carry_end);
-    if (st.carry_end == 0) {
-        const unsigned long long has = __ballot(run[3] != 0);
-        if (has != 0ull) {
-            int lf = ref[3];
-            lf = aln[2] ? ref[2] : lf;
-            lf = aln[1] ? ref[1] : lf;
-            lf = aln[0] ? ref[0] : lf;
-            st.first = __builtin_amdgcn_readlane(lf, (int)__builtin_ctzll(has));
-        }
-    }
-    const int none = 0x3fffffff;
-    const int pin = prev_in == 0 ? none : prev_in;
-    const int pv1 = run[0] ? run[0] : pin, pv2 = run[1] ? run[1] : pin, pv3 = run[2] ? run[2] : pin;
-    const bool h0 = aln[0] && (ref[0] - pin > min_gap);
-    const bool h1 = aln[1] && (ref[1] - pv1 > min_gap);
-    const bool h2 = aln[2] && (ref[2] - pv2 > min_gap);
-    const bool h3 = aln[3] && (ref[3] - pv3 > min_gap);
-    if (gaps_on && __ballot(h0 | h1 | h2 | h3) != 0ull) {
-        const int pv[4] = {pin, pv1, pv2, pv3};
-        const bool hit[4] = {h0, h1, h2, h3};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (hit[k]) {
-                const uint32_t slot = atomicAdd(gap_count, 1u);
-                if (slot < gap_cap) {
-                    int4 row = make_int4(rec, (quad_in_rec + lane) * 4 + k, p0 + pv[k], p0 + ref[k]);
-                    reinterpret_cast<int4 *>(gaps)[slot] = row;
-                }
-            }
-        }
-    }
-    st.carry_ref += __builtin_amdgcn_readlane(incl, 63);
-    st.carry_end = max(st.carry_end, __builtin_amdgcn_readlane(mx, 63));
-}
-
-template <int BATCH>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_flat(
-    long long n_rec, const int32_t *__restrict__ pos, const int32_t *__restrict__ flagmq,
-    const int32_t *__restrict__ n_cigar, const int64_t *__restrict__ cigar_off,
-    const uint32_t *__restrict__ cigar, int min_gap, int min_mapq, int32_t *__restrict__ mbases,
-    int32_t *__restrict__ qinfer, int32_t *__restrict__ blk_first, int32_t *__restrict__ blk_last,
-    int32_t *__restrict__ gaps, uint32_t *__restrict__ gap_count, uint32_t gap_cap) {
-    const int lane = threadIdx.x & 63;
-    const long long wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (SCAN_BLOCK / WAVE) + (threadIdx.x >> 6)));
-    const long long nwaves = (long long)gridDim.x * (SCAN_BLOCK / WAVE);
-    const cquad_t pad = {OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD};
-    const cquad_t *__restrict__ qbase = reinterpret_cast<const cquad_t *>(cigar);
-
-    // ---- this wave's record range [ra, rb): first record starting at or after its share of the op stream
-    const long long total = cigar_off[n_rec];
-    auto first_record_at = [&](long long target) -> long long {     // lower_bound over cigar_off[0..n_rec]
-        long long lo = 0, hi = n_rec;
-        while (lo < hi) {
-            const long long mid = (lo + hi) >> 1;
-            if (cigar_off[mid] >= target) hi = mid; else lo = mid + 1;
-        }
-        return lo;
-    };
-    const long long ra = wave == 0 ? 0 : first_record_at((total / nwaves) * wave);
-    const long long rb = wave == nwaves - 1 ? n_rec : first_record_at((total / nwaves) * (wave + 1));
-    if (ra >= rb) return;            // (wave-uniform)
-    const long long s0 = cigar_off[ra] >> 2, s1 = cigar_off[rb] >> 2;      // quad range of the wave
-
-    // ---- record cursor; the next record's metadata is requested one record ahead (scalar loads)
-    long long r = ra;
-    long long rstart = s0, rend = cigar_off[ra + 1] >> 2;
-    int p0 = pos[ra];
-    bool gaps_on = ((flagmq[ra] >> 16) & 0xff) >= min_mapq;
-    long long n_off = 0;
-    int n_pos = 0, n_fm = 0;
-    const long long last_rec = n_rec - 1;
-    auto request = [&](long long rr) {
-        const long long c = rr < n_rec ? rr : last_rec;
-        n_off = cigar_off[c + 1];
-        n_pos = pos[c];
-        n_fm = flagmq[c];
-    };
-    request(ra + 1);
-    RecState st = {0, 0, 0, 0, 0};
-    auto finish_record = [&]() {
-        const int ms = wave_sum_dpp(st.msum);
-        const int qs = wave_sum_dpp(st.qsum);
-        if (lane == 0) {
-            mbases[r] = ms;
-            qinfer[r] = qs;
-            blk_first[r] = (st.carry_end > 0) ? p0 + st.first : -1;
-            blk_last[r] = (st.carry_end > 0) ? p0 + st.carry_end : -1;
-        }
-        st = {0, 0, 0, 0, 0};
-        ++r;
-        rstart = rend;
-        rend = n_off >> 2;
-        p0 = n_pos;
-        gaps_on = ((n_fm >> 16) & 0xff) >= min_mapq;
-        request(r + 1);
-    };
-
-    // ---- flat stream, BATCH KiB ahead
-    cquad_t cur[BATCH], nxt[BATCH];
-    auto fetch = [&](cquad_t (&dst)[BATCH], long long q0) {
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) {
-            dst[j] = pad;
-            const long long i = q0 + j * WAVE + lane;
-            if (i < s1) dst[j] = qbase[i];
-        }
-    };
-    fetch(cur, s0);
-    for (long long cq0 = s0; cq0 < s1; cq0 += BATCH * WAVE) {
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) asm volatile("" : "+v"(cur[j]));      // wait for this batch here, then prefetch
-        fetch(nxt, cq0 + BATCH * WAVE);
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) {
-            const long long cq = cq0 + j * WAVE;
-            if (cq >= s1) break;
-            const long long cend = cq + WAVE;
-            long long seg_start = cq;
-            for (;;) {                                           // once per record present in this chunk (usually once)
-                const long long seg_end = rend < cend ? rend : cend;
-                if (seg_end > seg_start) {
-                    const long long qi = cq + lane;
-                    cquad_t b = cur[j];
-                    if (qi < seg_start || qi >= seg_end) b = pad;
-                    scan_chunk(b, lane, st, gaps_on, min_gap, (int)r, (int)(cq - rstart), p0, gaps, gap_count, gap_cap);
-                }
-                if (rend > cend) break;                          // the record continues in the next chunk
-                finish_record();
-                if (r >= rb) break;
-                seg_start = rstart;
-                if (seg_start >= cend) break;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) cur[j] = nxt[j];
-    }
-    while (r < rb) finish_record();      // records without any op at the end of the range
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1 (variant 8, "packed")  like variant 3, but the fetch and process cursors advance CHUNK BY CHUNK: the BATCH loads a
-// wave has in flight are the next BATCH chunks of its record sequence, whichever records they belong to.  Variants 2-4
-// never let a batch span two records, so a record of L KiB occupies ceil(L / BATCH) whole batches and the load slots
-// of the unused tail stay empty (about a third of them at 8 KiB batches and 7.4 KiB mean records); here only the last,
-// partial chunk of a record is padding.  A chunk still belongs to one record, so the arithmetic (scan_chunk) is
-// unchanged; the end-of-record summary moves inside the chunk loop.
-// ---------------------------------------------------------------------------------------------
-template <int BATCH>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_packed(
-    long long n_rec, const int32_t *__restrict__ pos, const int32_t *__restrict__ flagmq,
-    const int32_t *__restrict__ n_cigar, const int64_t *__restrict__ cigar_off,
-    const uint32_t *__restrict__ cigar, int min_gap, int min_mapq, int32_t *__restrict__ mbases,
-    int32_t *__restrict__ qinfer, int32_t *__restrict__ blk_first, int32_t *__restrict__ blk_last,
-    int32_t *__restrict__ gaps, uint32_t *__restrict__ gap_count, uint32_t gap_cap) {
-    const int lane = threadIdx.x & 63;
-    const long long wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (SCAN_BLOCK / WAVE) + (threadIdx.x >> 6)));
-    const long long nwaves = (long long)gridDim.x * (SCAN_BLOCK / WAVE);
-    const cquad_t pad = {OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD};
-    const long long last_rec = n_rec - 1;      // n_rec >= 1 (checked by the launcher)
-
-    // fetch cursor (record, chunk): metadata is wave-uniform, loaded with scalar loads one record ahead of its use
-    long long fr = wave;
-    int fc = 0, fnq = 0;
-    const cquad_t *__restrict__ fq = reinterpret_cast<const cquad_t *>(cigar);
-    int f_nn = 0;
-    long long f_noff = 0;
-    auto f_request = [&](long long r) {
-        const long long rr = r < n_rec ? r : last_rec;
-        f_nn = n_cigar[rr];
-        f_noff = cigar_off[rr];
-    };
-    auto f_meta = [&]() {
-        fc = 0;
-        fnq = fr < n_rec ? (f_nn + 3) >> 2 : 0;
-        fq = reinterpret_cast<const cquad_t *>(cigar + f_noff);
-        f_request(fr + nwaves);
-    };
-    auto f_chunk = [&](cquad_t &dst) {          // load the chunk under the cursor, then step (every record has >= 1 chunk)
-        dst = pad;
-        if (fc + lane < fnq) dst = fq[fc + lane];
-        fc += WAVE;
-        if (fc >= fnq) {
-            fr += nwaves;
-            f_meta();
-        }
-    };
-    // process cursor
-    long long pr = wave;
-    int pc = 0, pnq = 0, p0 = 0;
-    bool gaps_on = false;
-    int p_nn = 0, p_npos = 0, p_nfm = 0;
-    auto p_request = [&](long long r) {
-        const long long rr = r < n_rec ? r : last_rec;
-        p_nn = n_cigar[rr];
-        p_npos = pos[rr];
-        p_nfm = flagmq[rr];
-    };
-    auto p_meta = [&]() {
-        pc = 0;
-        pnq = (p_nn + 3) >> 2;
-        p0 = p_npos;
-        gaps_on = ((p_nfm >> 16) & 0xff) >= min_mapq;
-        p_request(pr + nwaves);
-    };
-    f_request(fr);
-    p_request(pr);
-    f_meta();
-    p_meta();
-    cquad_t cur[BATCH], nxt[BATCH];
-#pragma unroll
-    for (int j = 0; j < BATCH; ++j) f_chunk(cur[j]);
-
-    RecState st = {0, 0, 0, 0, 0};
-    while (pr < n_rec) {
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) asm volatile("" : "+v"(cur[j]));     // wait for this batch before issuing the next
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) f_chunk(nxt[j]);
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) {
-            if (pr >= n_rec) break;                     // wave-uniform: this wave's records are done
-            scan_chunk(cur[j], lane, st, gaps_on, min_gap, (int)pr, pc, p0, gaps, gap_count, gap_cap);
-            pc += WAVE;
-            if (pc >= pnq) {                            // last chunk of the record: write its summary, move on
-                const int ms = wave_sum_dpp(st.msum);
-                const int qs = wave_sum_dpp(st.qsum);
-                if (lane == 0) {
-                    mbases[pr] = ms;
-                    qinfer[pr] = qs;
-                    blk_first[pr] = (st.carry_end > 0) ? p0 + st.first : -1;
-                    blk_last[pr] = (st.carry_end > 0) ? p0 + st.carry_end : -1;
-                }
-                st = {0, 0, 0, 0, 0};
-                pr += nwaves;
-                p_meta();
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) cur[j] = nxt[j];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1 (variant 10, "ring")  the production scan kernel.
-//   * chunk-granular fetch / process cursors as in the packed variant: the BATCH loads a wave keeps in flight are the
-//     next BATCH chunks of its record sequence, whatever records they belong to;
-//   * the register ring is refilled IN PLACE: chunk slot j is reloaded right after its arithmetic, so there is no second
-//     buffer (half the data registers of variants 2-8 -> more waves per SIMD) and no register copies;
-//   * a full chunk is loaded with an SGPR base + the constant lane offset and no exec masking (zero vector instructions per
-//     load); only a record's last, partial chunk takes the masked path with padding;
-//   * the arithmetic first applies the conservative gap filter of variant 7 (see k_cigar_scan_v2) and runs the exact
-//     max-scan / distance tests only on the chunks that fail it.
-// The kernel is vector-ALU bound when launched on its own (profiles/r01_scan_variants.md): every instruction removed
-// from the per-chunk path shows up in the launch time.
-// ---------------------------------------------------------------------------------------------
-struct RingState {
-    int carry_ref, carry_end, msum, qsum, first;
-    bool tail_flagged;
-};
-
-template <bool FILTER>
-__device__ __forceinline__ void ring_chunk(const cquad_t b0, const int lane, RingState &st, const bool gaps_on, const int min_gap,
-                                           const int half_gap, const int rec, const int quad_in_rec, const int p0,
-                                           int32_t *__restrict__ gaps, uint32_t *__restrict__ gap_count, const uint32_t gap_cap) {
-    int len[4], adv[4], fal[4];
-    int tot = 0, asum = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t w = b0[k];
-        len[k] = (int)(w >> 4);
-        // v_bfe_i32 takes its bit offset from the low 5 bits of the operand (op code + 16 * (length & 1)); the class masks are
-        // replicated into both halves, so the op word itself serves as the offset: 0 / -1 per class in one instruction.
-        const int fr_ = __builtin_amdgcn_sbfe((int)(MASK_REF * 0x10001u), w, 1u);
-        const int fa_ = __builtin_amdgcn_sbfe((int)(MASK_ALN * 0x10001u), w, 1u);
-        const int fq_ = __builtin_amdgcn_sbfe((int)(MASK_QRY * 0x10001u), w, 1u);
-        adv[k] = len[k] & fr_;
-        fal[k] = fa_;
-        asum += len[k] & fa_;
-        st.qsum += len[k] & fq_;
-        tot += adv[k];
-    }
-    st.msum += asum;
-    const int incl = wave_incl_scan_add_dpp(tot);
-    const int ref0 = st.carry_ref + incl - tot;
-    const int m3 = fal[3], m2 = m3 | fal[2], m1 = m2 | fal[1], m0 = m1 | fal[0];
-    bool exact = true;
-    if (FILTER) {
-        const unsigned long long flagged = (__ballot(m0 == 0) & __ballot(b0[0] != OP_PAD_QUAD)) | __ballot(tot - asum > half_gap);
-        exact = flagged != 0ull || st.tail_flagged;
-        st.tail_flagged = (flagged >> 63) != 0ull;
-        if (!exact) {
-            const unsigned long long has = __ballot(m0 != 0);       // 0 only for a record without any op (all padding)
-            if (has != 0ull) {
-                if (st.carry_end == 0) {     // (wave-uniform) the record's first block starts in this chunk
-                    const int n0 = ~fal[0], n1 = n0 & ~fal[1], n2 = n1 & ~fal[2];
-                    const int lf = ref0 + (adv[0] & n0) + (adv[1] & n1) + (adv[2] & n2);
-                    st.first = __builtin_amdgcn_readlane(lf, (int)__builtin_ctzll(has));
-                }
-                const int off_end = adv[0] + (adv[1] & m1) + (adv[2] & m2) + (adv[3] & m3);
-                st.carry_end = __builtin_amdgcn_readlane(ref0 + off_end, 63 - (int)__builtin_clzll(has));
-            }
-        }
-    }
-    if (exact) {
-        const bool aln[4] = {fal[0] != 0, fal[1] != 0, fal[2] != 0, fal[3] != 0};
-        int ref[4];
-        ref[0] = ref0;
-        ref[1] = ref[0] + adv[0];
-        ref[2] = ref[1] + adv[1];
-        ref[3] = ref[2] + adv[2];
-        int run[4];                          // running "end of the last aligned block" inside the lane (0 = none yet)
-        run[0] = aln[0] ? ref[0] + len[0] : 0;
-        run[1] = aln[1] ? ref[1] + len[1] : run[0];
-        run[2] = aln[2] ? ref[2] + len[2] : run[1];
-        run[3] = aln[3] ? ref[3] + len[3] : run[2];
-        int mx = run[3];                     // previous block end seen by a lane = max over the earlier lanes, else the carry
-        mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x111, 0xf, 0xf, true));
-        mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x112, 0xf, 0xf, true));
-        mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x114, 0xf, 0xf, true));
-        mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x118, 0xf, 0xf, true));
-        mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x142, 0xa, 0xf, true));
-        mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x143, 0xc, 0xf, true));
-        const int shifted = __builtin_amdgcn_update_dpp(st.carry_end, mx, 0x138, 0xf, 0xf, false);   // wave_shr:1
-        const int prev_in = max(shifted, st.carry_end);
-        if (st.carry_end == 0) {
-            const unsigned long long has = __ballot(run[3] != 0);
-            if (has != 0ull) {
-                int lf = ref[3];
-                lf = aln[2] ? ref[2] : lf;
-                lf = aln[1] ? ref[1] : lf;
-                lf = aln[0] ? ref[0] : lf;
-                st.first = __builtin_amdgcn_readlane(lf, (int)__builtin_ctzll(has));
-            }
-        }
-        const int none = 0x3fffffff;
-        const int pin = prev_in == 0 ? none : prev_in;
-        const int pv1 = run[0] ? run[0] : pin, pv2 = run[1] ? run[1] : pin, pv3 = run[2] ? run[2] : pin;
-        const bool h0 = aln[0] && (ref[0] - pin > min_gap);
-        const bool h1 = aln[1] && (ref[1] - pv1 > min_gap);
-        const bool h2 = aln[2] && (ref[2] - pv2 > min_gap);
-        const bool h3 = aln[3] && (ref[3] - pv3 > min_gap);
-        if (gaps_on && __ballot(h0 | h1 | h2 | h3) != 0ull) {
-            const int pv[4] = {pin, pv1, pv2, pv3};
-            const bool hit[4] = {h0, h1, h2, h3};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (hit[k]) {
-                    const uint32_t slot = atomicAdd(gap_count, 1u);
-                    if (slot < gap_cap) {
-                        int4 row = make_int4(rec, (quad_in_rec + lane) * 4 + k, p0 + pv[k], p0 + ref[k]);
-                        reinterpret_cast<int4 *>(gaps)[slot] = row;
-                    }
-                }
-            }
-        }
-        st.carry_end = max(st.carry_end, __builtin_amdgcn_readlane(mx, 63));
-    }
-    st.carry_ref += __builtin_amdgcn_readlane(incl, 63);
-}
-
-template <int BATCH, bool FILTER>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_ring(
-    long long n_rec, const int32_t *__restrict__ pos, const int32_t *__restrict__ flagmq,
-    const int32_t *__restrict__ n_cigar, const int64_t *__restrict__ cigar_off,
-    const uint32_t *__restrict__ cigar, int min_gap, int min_mapq, int32_t *__restrict__ mbases,
-    int32_t *__restrict__ qinfer, int32_t *__restrict__ blk_first, int32_t *__restrict__ blk_last,
-    int32_t *__restrict__ gaps, uint32_t *__restrict__ gap_count, uint32_t gap_cap) {
-    const int lane = threadIdx.x & 63;
-    const long long wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (SCAN_BLOCK / WAVE) + (threadIdx.x >> 6)));
-    const long long nwaves = (long long)gridDim.x * (SCAN_BLOCK / WAVE);
-    const cquad_t pad = {OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD};
-    const long long last_rec = n_rec - 1;      // n_rec >= 1 (checked by the launcher)
-    const int half_gap = min_gap >> 1;
-
-    // fetch cursor (record, chunk): metadata is wave-uniform, loaded with scalar loads one record ahead of its use
-    long long fr = wave;
-    int fc = 0, fnq = 0;
-    const cquad_t *__restrict__ fq = reinterpret_cast<const cquad_t *>(cigar);
-    int f_nn = 0;
-    long long f_noff = 0;
-    auto f_request = [&](long long r) {
-        const long long rr = r < n_rec ? r : last_rec;
-        f_nn = n_cigar[rr];
-        f_noff = cigar_off[rr];
-    };
-    auto f_meta = [&]() {
-        fc = 0;
-        fnq = fr < n_rec ? (f_nn + 3) >> 2 : 0;
-        fq = reinterpret_cast<const cquad_t *>(cigar + f_noff);
-        f_request(fr + nwaves);
-    };
-    auto f_chunk = [&](cquad_t &dst) {          // load the chunk under the cursor into a ring slot, then step
-        const cquad_t *__restrict__ base = fq + fc;            // wave-uniform
-        if (fc + WAVE <= fnq) {
-            dst = base[lane];                   // full chunk: SGPR base + lane offset, no masking
-        } else {                                // last (partial) chunk of a record, or a record without ops
-            dst = pad;
-            if (fc + lane < fnq) dst = base[lane];
-        }
-        fc += WAVE;
-        if (fc >= fnq) {
-            fr += nwaves;
-            f_meta();
-        }
-    };
-    // process cursor
-    long long pr = wave;
-    int pc = 0, pnq = 0, p0 = 0;
-    bool gaps_on = false;
-    int p_nn = 0, p_npos = 0, p_nfm = 0;
-    auto p_request = [&](long long r) {
-        const long long rr = r < n_rec ? r : last_rec;
-        p_nn = n_cigar[rr];
-        p_npos = pos[rr];
-        p_nfm = flagmq[rr];
-    };
-    auto p_meta = [&]() {
-        pc = 0;
-        pnq = (p_nn + 3) >> 2;
-        p0 = p_npos;
-        gaps_on = ((p_nfm >> 16) & 0xff) >= min_mapq;
-        p_request(pr + nwaves);
-    };
-    f_request(fr);
-    p_request(pr);
-    f_meta();
-    p_meta();
-    cquad_t ring[BATCH];
-#pragma unroll
-    for (int j = 0; j < BATCH; ++j) f_chunk(ring[j]);
-
-    RingState st = {0, 0, 0, 0, 0, false};
-    while (pr < n_rec) {
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) {
-            if (pr >= n_rec) break;                     // wave-uniform: this wave's records are done
-            ring_chunk<FILTER>(ring[j], lane, st, gaps_on, min_gap, half_gap, (int)pr, pc, p0, gaps, gap_count, gap_cap);
-            pc += WAVE;
-            if (pc >= pnq) {                            // last chunk of the record: write its summary, move on
-                const int ms = wave_sum_dpp(st.msum);
-                const int qs = wave_sum_dpp(st.qsum);
-                if (lane == 0) {
-                    mbases[pr] = ms;
-                    qinfer[pr] = qs;
-                    blk_first[pr] = (st.carry_end > 0) ? p0 + st.first : -1;
-                    blk_last[pr] = (st.carry_end > 0) ? p0 + st.carry_end : -1;
-                }
-                st = {0, 0, 0, 0, 0, false};
-                pr += nwaves;
-                p_meta();
-            }
-            f_chunk(ring[j]);                           // refill the slot: in flight during the next BATCH - 1 chunks
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1 (variant 13, "ring + counted waits")  k_cigar_scan_ring with the ring loads issued and awaited by hand.
-// The compiler's s_waitcnt insertion cannot see across the loop back-edge that exactly BATCH - 1 younger loads are in
-// flight when a slot is consumed, and drains the whole ring (vmcnt(0)) once per round.  Here every f_chunk issues EXACTLY
-// ONE global_load_dwordx4 (inline asm; a partial or absent chunk loads from a clamped, always valid address and is masked
-// to padding when it is consumed), so the slot consumed next is always the oldest outstanding load and
-// `s_waitcnt vmcnt(BATCH - 1)` is exact.  Vector-memory operations the compiler issues on its own (record summaries, gap
-// rows) only make either side's count conservative: completion is in order, so "at most N outstanding" still implies the
-// awaited operation is done.
-// ---------------------------------------------------------------------------------------------
-template <int N>
-__device__ __forceinline__ void ring_wait(cquad_t &slot) {
-    if (N == 7) asm volatile("s_waitcnt vmcnt(7)" : "+v"(slot));
-    else if (N == 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(slot));
-    else if (N == 5) asm volatile("s_waitcnt vmcnt(5)" : "+v"(slot));
-    else if (N == 11) asm volatile("s_waitcnt vmcnt(11)" : "+v"(slot));
-    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(slot));
-}
-
-template <int BATCH, bool FILTER>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_ring_asm(
-    long long n_rec, const int32_t *__restrict__ pos, const int32_t *__restrict__ flagmq,
-    const int32_t *__restrict__ n_cigar, const int64_t *__restrict__ cigar_off,
-    const uint32_t *__restrict__ cigar, int min_gap, int min_mapq, int32_t *__restrict__ mbases,
-    int32_t *__restrict__ qinfer, int32_t *__restrict__ blk_first, int32_t *__restrict__ blk_last,
-    int32_t *__restrict__ gaps, uint32_t *__restrict__ gap_count, uint32_t gap_cap) {
-    const int lane = threadIdx.x & 63;
-    const int lane16 = lane << 4;
-    const long long wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (SCAN_BLOCK / WAVE) + (threadIdx.x >> 6)));
-    const long long nwaves = (long long)gridDim.x * (SCAN_BLOCK / WAVE);
-    const cquad_t pad = {OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD};
-    const long long last_rec = n_rec - 1;      // n_rec >= 1 (checked by the launcher)
-    const int half_gap = min_gap >> 1;
-    const cquad_t *dummy = reinterpret_cast<const cquad_t *>(cigar);       // 16 readable bytes for chunks that do not exist
-
-    long long fr = wave;
-    int fc = 0, fnq = 0;
-    const cquad_t *__restrict__ fq = reinterpret_cast<const cquad_t *>(cigar);
-    int f_nn = 0;
-    long long f_noff = 0;
-    auto f_request = [&](long long r) {
-        const long long rr = r < n_rec ? r : last_rec;
-        f_nn = n_cigar[rr];
-        f_noff = cigar_off[rr];
-    };
-    auto f_meta = [&]() {
-        fc = 0;
-        fnq = fr < n_rec ? (f_nn + 3) >> 2 : 0;
-        fq = reinterpret_cast<const cquad_t *>(cigar + f_noff);
-        f_request(fr + nwaves);
-    };
-    auto f_chunk = [&](cquad_t &dst) {          // exactly one load per call
-        const cquad_t *base = fq + fc;          // wave-uniform
-        int voff = lane16;
-        if (fc + WAVE > fnq) {                  // (wave-uniform) partial or absent chunk: clamp to the last valid quad
-            const int nvalid = fnq - fc;
-            if (nvalid > 0) {
-                voff = min(lane, nvalid - 1) << 4;
-            } else {
-                base = dummy;
-                voff = 0;
-            }
-        }
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base));    // no "memory" clobber: it
-                                                     // would stop the compiler from using scalar loads for the metadata
-        fc += WAVE;
-        if (fc >= fnq) {
-            fr += nwaves;
-            f_meta();
-        }
-    };
-    long long pr = wave;
-    int pc = 0, pnq = 0, p0 = 0;
-    bool gaps_on = false;
-    int p_nn = 0, p_npos = 0, p_nfm = 0;
-    auto p_request = [&](long long r) {
-        const long long rr = r < n_rec ? r : last_rec;
-        p_nn = n_cigar[rr];
-        p_npos = pos[rr];
-        p_nfm = flagmq[rr];
-    };
-    auto p_meta = [&]() {
-        pc = 0;
-        pnq = (p_nn + 3) >> 2;
-        p0 = p_npos;
-        gaps_on = ((p_nfm >> 16) & 0xff) >= min_mapq;
-        p_request(pr + nwaves);
-    };
-    f_request(fr);
-    p_request(pr);
-    f_meta();
-    p_meta();
-    cquad_t ring[BATCH];
-#pragma unroll
-    for (int j = 0; j < BATCH; ++j) f_chunk(ring[j]);
-
-    RingState st = {0, 0, 0, 0, 0, false};
-    while (pr < n_rec) {
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) {
-            if (pr >= n_rec) break;                     // wave-uniform: this wave's records are done
-            ring_wait<BATCH - 1>(ring[j]);              // the oldest outstanding load is this slot's
-            cquad_t q = ring[j];
-            if (pc + WAVE > pnq) {                      // (wave-uniform) last chunk of the record: lanes past its end are padding
-                asm volatile("");                       // keep this a branch: selects on every chunk would cost 6 instructions
-                const bool valid = pc + lane < pnq;
-                q[0] = valid ? q[0] : pad[0];
-                q[1] = valid ? q[1] : pad[1];
-                q[2] = valid ? q[2] : pad[2];
-                q[3] = valid ? q[3] : pad[3];
-            }
-            ring_chunk<FILTER>(q, lane, st, gaps_on, min_gap, half_gap, (int)pr, pc, p0, gaps, gap_count, gap_cap);
-            pc += WAVE;
-            if (pc >= pnq) {
-                const int ms = wave_sum_dpp(st.msum);
-                const int qs = wave_sum_dpp(st.qsum);
-                if (lane == 0) {
-                    mbases[pr] = ms;
-                    qinfer[pr] = qs;
-                    blk_first[pr] = (st.carry_end > 0) ? p0 + st.first : -1;
-                    blk_last[pr] = (st.carry_end > 0) ? p0 + st.carry_end : -1;
-                }
-                st = {0, 0, 0, 0, 0, false};
-                pr += nwaves;
-                p_meta();
-            }
-            f_chunk(ring[j]);                           // refill the slot
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)");                 // nothing may still be landing in registers when the wave ends
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1 (variant 20, "tile stream")  a wave takes tiles of TILE consecutive records (as variant 15) and reads a tile as ONE
-// contiguous run of 16-byte quads: the records of a tile are adjacent in the CIGAR array, so every load is a full,
-// unmasked 1 KiB chunk (SGPR base + lane offset) except the tile's last one, and the loads never notice record
-// boundaries.  The arithmetic walks the same chunk stream; a chunk that holds a record boundary is processed once per
-// record piece with the other lanes masked to padding (quad-aligned boundaries: the layout pads every record).
-// Per-record metadata (op count, position, flag/MAPQ, next offset) is read with scalar loads one record ahead.
-// ---------------------------------------------------------------------------------------------
-template <int BATCH, int TILE, bool FILTER>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_tile(
-    long long n_rec, const int32_t *__restrict__ pos, const int32_t *__restrict__ flagmq,
-    const int32_t *__restrict__ n_cigar, const int64_t *__restrict__ cigar_off,
-    const uint32_t *__restrict__ cigar, int min_gap, int min_mapq, int32_t *__restrict__ mbases,
-    int32_t *__restrict__ qinfer, int32_t *__restrict__ blk_first, int32_t *__restrict__ blk_last,
-    int32_t *__restrict__ gaps, uint32_t *__restrict__ gap_count, uint32_t gap_cap) {
-    const int lane = threadIdx.x & 63;
-    const long long wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (SCAN_BLOCK / WAVE) + (threadIdx.x >> 6)));
-    const long long nwaves = (long long)gridDim.x * (SCAN_BLOCK / WAVE);
-    const cquad_t pad = {OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD};
-    const int half_gap = min_gap >> 1;
-    const long long n_tiles = (n_rec + TILE - 1) / TILE;       // n_rec >= 1 (checked by the launcher)
-    const long long last_tile = n_tiles - 1;
-    const cquad_t *__restrict__ qbase = reinterpret_cast<const cquad_t *>(cigar);
-
-    // ---- fetch cursor: (tile, quad offset inside the tile); a tile has max(1, ceil(quads / 64)) chunks
-    long long ft = wave;
-    const cquad_t *__restrict__ fbase = qbase;
-    int fq = 0, flen = 0;                     // next quad to fetch / quads of the tile
-    long long f_a = 0, f_b = 0;               // op offsets of the first record of tile ft + nwaves and of the tile after it
-    auto f_request = [&](long long t) {
-        const long long tt = t < n_tiles ? t : last_tile;
-        const long long r1 = (tt + 1) * TILE;
-        f_a = cigar_off[tt * TILE];
-        f_b = cigar_off[r1 < n_rec ? r1 : n_rec];
-    };
-    auto f_meta = [&]() {
-        fq = 0;
-        flen = ft < n_tiles ? (int)((f_b - f_a) >> 2) : 0;
-        fbase = qbase + (f_a >> 2);
-        f_request(ft + nwaves);
-    };
-    auto f_chunk = [&](cquad_t &dst) {
-        const cquad_t *__restrict__ base = fbase + fq;          // wave-uniform
-        if (fq + WAVE <= flen) {
-            dst = base[lane];
-        } else {
-            dst = pad;
-            if (fq + lane < flen) dst = base[lane];
-        }
-        fq += WAVE;
-        if (fq >= flen) {
-            ft += nwaves;
-            f_meta();
-        }
-    };
-    // ---- process cursor: tile, chunk, and the record the chunk stream is currently inside
-    long long pt = wave;
-    int pq = 0, plen = 0;                     // first quad of the current chunk / quads of the tile (tile-relative)
-    long long p_a = 0, p_b = 0;               // as f_a / f_b for the process cursor
-    long long tile_q0 = 0;                    // absolute quad of the tile start
-    auto t_request = [&](long long t) {
-        const long long tt = t < n_tiles ? t : last_tile;
-        const long long r1 = (tt + 1) * TILE;
-        p_a = cigar_off[tt * TILE];
-        p_b = cigar_off[r1 < n_rec ? r1 : n_rec];
-    };
-    long long pr = wave * TILE, tile_end_rec = 0;              // current record, one past the tile's last record
-    int rs = 0, re = 0, p0 = 0;               // the record's first quad and one past its last real quad (tile-relative)
-    bool gaps_on = false;
-    int r_nn = 0, r_pos = 0, r_fm = 0;        // metadata of record pr + 1 ... requested one record ahead
-    long long r_off = 0, r_noff = 0;
-    const long long last_rec = n_rec - 1;
-    auto r_request = [&](long long r) {
-        const long long rr = r < n_rec ? r : last_rec;
-        r_nn = n_cigar[rr];
-        r_pos = pos[rr];
-        r_fm = flagmq[rr];
-        r_off = cigar_off[rr];
-    };
-    auto r_meta = [&]() {                      // enter record pr (values requested earlier), request the next one
-        rs = (int)((r_off >> 2) - tile_q0);
-        re = rs + ((r_nn + 3) >> 2);
-        p0 = r_pos;
-        gaps_on = ((r_fm >> 16) & 0xff) >= min_mapq;
-        r_request(pr + 1);
-    };
-    auto t_meta = [&]() {                      // enter tile pt
-        pq = 0;
-        tile_q0 = p_a >> 2;
-        plen = pt < n_tiles ? (int)((p_b - p_a) >> 2) : 0;
-        pr = pt * TILE;
-        tile_end_rec = (pt + 1) * TILE < n_rec ? (pt + 1) * TILE : n_rec;
-        t_request(pt + nwaves);
-        r_request(pr);
-        r_meta();
-    };
-    f_request(ft);
-    t_request(pt);
-    f_meta();
-    t_meta();
-    cquad_t cur[BATCH], nxt[BATCH];
-#pragma unroll
-    for (int j = 0; j < BATCH; ++j) f_chunk(cur[j]);
-
-    RingState st = {0, 0, 0, 0, 0, false};
-    while (pt < n_tiles) {
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) asm volatile("" : "+v"(cur[j]));     // wait for this batch before issuing the next
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) f_chunk(nxt[j]);
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) {
-            if (pt >= n_tiles) break;                   // wave-uniform: this wave's tiles are done
-            const int cend = pq + WAVE;
-            // every record piece inside the chunk [pq, cend)
-            for (;;) {
-                const bool in_tile = pr < tile_end_rec;
-                if (!in_tile) break;
-                const int lo = rs > pq ? rs : pq;
-                const int hi = re < cend ? re : cend;
-                if (hi > lo) {
-                    cquad_t q = cur[j];
-                    if (lo != pq || hi != cend) {        // (wave-uniform) the piece does not fill the chunk: pad the other lanes
-                        asm volatile("");
-                        const int x = pq + lane;
-                        const bool valid = x >= lo && x < hi;
-                        q[0] = valid ? q[0] : pad[0];
-                        q[1] = valid ? q[1] : pad[1];
-                        q[2] = valid ? q[2] : pad[2];
-                        q[3] = valid ? q[3] : pad[3];
-                    }
-                    ring_chunk<FILTER>(q, lane, st, gaps_on, min_gap, half_gap, (int)pr, pq - rs, p0, gaps, gap_count, gap_cap);
-                }
-                if (re > cend) break;                    // the record continues in the next chunk
-                // the record ends inside this chunk: write its summary, enter the next record
-                const int ms = wave_sum_dpp(st.msum);
-                const int qs = wave_sum_dpp(st.qsum);
-                if (lane == 0) {
-                    mbases[pr] = ms;
-                    qinfer[pr] = qs;
-                    blk_first[pr] = (st.carry_end > 0) ? p0 + st.first : -1;
-                    blk_last[pr] = (st.carry_end > 0) ? p0 + st.carry_end : -1;
-                }
-                st = {0, 0, 0, 0, 0, false};
-                ++pr;
-                r_meta();
-            }
-            pq = cend;
-            if (pq >= plen) {                            // last chunk of the tile
-                pt += nwaves;
-                t_meta();
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) cur[j] = nxt[j];
-    }
-}
+// The alternative kernel structures that were measured and rejected (flat, packed, ring, ring + counted waits, tile stream)
+#include "coral_scan_experiments.hip.inc"
 
 // Streaming-read probe: what a plain grid-stride 16-byte-per-lane read of the same CIGAR bytes achieves
 // (upper bound for any kernel that must touch every op once).
