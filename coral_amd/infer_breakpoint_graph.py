@@ -413,7 +413,9 @@ class bam_to_breakpoint_nanopore():
         # look-ahead worker for the pure part of every search step (_prepare_step); results are keyed by interval index and
         # coordinates, so a step is recomputed in line if its interval changed after it was queued (it never does today)
         self._ahead = {}
-        self._pool = None if _VERIFY_SET_ORDER else ThreadPoolExecutor(
+        # a few thousand chimeric reads: thread hand-offs cost more than they hide (threshold overridable for tests)
+        small = len(self._chim.read) < int(os.environ.get("CORAL_AHEAD_MIN_READS", "20000"))
+        self._pool = None if (_VERIFY_SET_ORDER or small) else ThreadPoolExecutor(
             max_workers=int(os.environ.get("CORAL_AHEAD_THREADS", "2")), thread_name_prefix="coral-ahead",
             initializer=_bind_thread_to_device, initargs=(self.rec.device,))
         try:
