@@ -144,3 +144,47 @@ def test_properties_at_full_size(tmp_path):
     for g in b1.lr_graph:
         for e in g.discordant_edges:
             assert e[9] == len(e[10]) >= b1.min_cluster_cutoff
+
+
+def _random_layout(seed):
+    """A seeded random amplicon layout (chromosomes, circles, segment lengths, seed count, read lengths) — none of them is a
+    golden; the oracle (itself pinned by the goldens) is the reference here."""
+    rng = np.random.default_rng(1000 + seed)
+    chroms = sorted(rng.choice(np.arange(22), size=int(rng.integers(1, 4)), replace=False).tolist())
+    n_circles = int(rng.integers(1, 4))
+    segs = int(rng.integers(2, 6))
+    return synth.build_config("rand%d" % seed, int(rng.integers(3000, 7000)), int(rng.choice([4000, 9000, 20000])), 77 + seed,
+                              chroms, n_circles, segs, (60_000, 200_000), int(rng.integers(1, 5)),
+                              window_len=16_000_000, n_planted=int(rng.integers(0, 4)),
+                              amp_frac=float(rng.choice([0.4, 0.6, 0.75])), min_len=600,
+                              planted_frac=float(rng.choice([0.3, 0.5])), inverted_frac=float(rng.choice([0.2, 0.5])))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_gpu_matches_oracle_random_layouts(seed, tmp_path):
+    """Product (HIP kernels, native host pieces, look-ahead threads forced on) vs the CPU oracle on random layouts."""
+    from coral_amd import infer_breakpoint_graph as ibg
+    from coral_amd.breakpoint_graph import graph_text
+    from coral_amd.records import DeviceRecords
+    from oracle import coral_oracle as O
+    from oracle.hostrecords import HostRecords
+    from tests.product_check import compare_graph_text
+    cfg = _random_layout(seed)
+    rec = synth.generate(cfg, "cpu")
+    cn = str(tmp_path / "cn.bed"); seeds = str(tmp_path / "seeds.bed")
+    synth.write_cn_bed(cfg, cn); synth.write_seed_bed(cfg, seeds)
+    os.environ["CORAL_AHEAD_MIN_READS"] = "0"
+    try:
+        b = ibg.build_graph_from_records(DeviceRecords(rec, "cuda:0"), seeds, cn, str(tmp_path / "gpu"))
+    finally:
+        del os.environ["CORAL_AHEAD_MIN_READS"]
+    ob, ofiles = O.reconstruct_graph(HostRecords(rec), seeds, cn)
+    assert len(b.lr_graph) == len(ob.lr_graph) and b.normal_cov == ob.normal_cov
+    assert sorted(map(str, b.amplicon_intervals)) == sorted(map(str, ob.amplicon_intervals))
+    for g, og in zip(b.lr_graph, ob.lr_graph):
+        assert [e[:8] for e in g.sequence_edges] == [e[:8] for e in og.sequence_edges]
+        assert [e[8] for e in g.concordant_edges] == [e[8] for e in og.concordant_edges]
+        assert sorted(map(str, (e[:6] + [e[9]] for e in g.discordant_edges))) == \
+            sorted(map(str, (e[:6] + [e[9]] for e in og.discordant_edges)))
+        if HASHSEED0:
+            compare_graph_text(graph_text(g), O.graph_text(og))
