@@ -69,6 +69,8 @@ def lib():
     L.coral_call_breakpoints.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_int64, C.c_int64, C.c_double,
                                          C.c_int32] + [C.c_void_p] * 10
     L.coral_call_breakpoints.restype = C.c_int
+    L.coral_nm_stats.argtypes = [C.c_int64] + [C.c_void_p] * 8
+    L.coral_nm_stats.restype = C.c_int
     L.coral_reach_create.argtypes = [C.c_int64] + [C.c_void_p] * 6 + [C.c_int64] * 4 + [C.c_void_p, C.c_void_p]
     L.coral_reach_create.restype = C.c_void_p
     L.coral_reach_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

@@ -57,12 +57,14 @@ def build_chimeric_table(dr) -> ChimericTable:
     """ibg:139-174 + cp:232-269 for all reads: coral_sa_table (K3) does the SA-row work on the GPU; this wrapper adds the
     float NM rate (cp:268) and the NM statistics of the non-chimeric MAPQ-60 records (ibg:153-157)."""
     from . import kernels
+    import ctypes as C
+    from . import _lib
     T = ChimericTable()
-    mapped = dr.h_tid >= 0
-    has_sa = (np.diff(dr.h_sa_off) > 0) & mapped
-    plain60 = mapped & ~has_sa & (dr.h_mapq == 60)
-    T.n_mapq60_plain = int(plain60.sum())
-    T.nm_e = dr.h_nm[plain60] / dr.h_qlen[plain60].astype(np.float64) if T.n_mapq60_plain else np.zeros(0)
+    cnt, s0, s1 = C.c_int64(0), C.c_double(0.0), C.c_double(0.0)
+    _lib.check(_lib.lib().coral_nm_stats(dr.n_total, dr.h_tid.ctypes.data, dr.h_sa_off.ctypes.data, dr.h_mapq.ctypes.data,
+                                         dr.h_nm.ctypes.data, dr.h_qlen.ctypes.data, C.byref(cnt), C.byref(s0), C.byref(s1)),
+               "coral_nm_stats")
+    T.n_mapq60_plain, T.nm_sum, T.nm_sum_sq = int(cnt.value), float(s0.value), float(s1.value)
     rows, off, name_id, failed, rl = kernels.sa_table(dr)
     T.read_length = rl
     T.name_id, T.failed, T.off = name_id, failed, off

@@ -320,3 +320,26 @@ extern "C" int coral_reach_keys(void *handle, int64_t *codes, int32_t *counts) {
     }
     return CORAL_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// NM statistics of the mapped, non-chimeric MAPQ-60 records (ibg:153-157): count, sum of e and sum of e*e with
+// e = NM / query_length, accumulated in file order with one rounding per addition — the float results the reference gets
+// from its sequential `+=` (build with -ffp-contract=off).  One pass over the host mirrors of the records.
+extern "C" int coral_nm_stats(int64_t n, const int32_t *tid, const int64_t *sa_off, const int32_t *mapq, const int32_t *nm,
+                              const int32_t *qlen, int64_t *count, double *sum_e, double *sum_e2) {
+    if (n < 0 || !count || !sum_e || !sum_e2 || (n > 0 && (!tid || !sa_off || !mapq || !nm || !qlen))) return CORAL_ERR_ARG;
+    int64_t c = 0;
+    double s0 = 0.0, s1 = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (tid[i] < 0 || sa_off[i + 1] > sa_off[i] || mapq[i] != 60) continue;
+        const double e = (double)nm[i] / (double)qlen[i];
+        const double e2 = e * e;
+        s0 += e;
+        s1 += e2;
+        ++c;
+    }
+    *count = c;
+    *sum_e = s0;
+    *sum_e2 = s1;
+    return CORAL_OK;
+}

@@ -340,9 +340,7 @@ class bam_to_breakpoint_nanopore():
         self._chim = T
         if T.n_mapq60_plain == 0:
             raise ZeroDivisionError("float division by zero")                # ibg:159
-        e = T.nm_e
-        s0 = float(np.cumsum(e)[-1])                                          # sequential adds, as the reference
-        s1 = float(np.cumsum(e * e)[-1])
+        s0, s1 = T.nm_sum, T.nm_sum_sq                                        # sequential adds, as the reference
         mean = s0 / T.n_mapq60_plain
         self.nm_stats = [mean, math.sqrt(s1 / T.n_mapq60_plain - mean ** 2), T.n_mapq60_plain]
         names = self.rec.names

@@ -231,6 +231,12 @@ int coral_call_breakpoints(int64_t n, const int64_t *const *field_ptr, const int
                            int32_t *n_clusters, int32_t *cluster_size, int32_t *n_calls, int64_t *call_head, int64_t *call_p1,
                            int64_t *call_p2, double *call_stats, int32_t *call_flags, int64_t *call_sup_off, int64_t *sup_idx);
 
+/* NM statistics of the mapped, non-chimeric (no SA tag) MAPQ-60 records, ibg:153-157: their count and the sums of
+ * e = NM / query_length and of e * e, added in record order with one rounding per addition (the reference's sequential
+ * `+=`).  Host arrays: tid / mapq / nm / qlen int32[n], sa_off int64[n + 1] (SA rows per record). */
+int coral_nm_stats(int64_t n, const int32_t *tid, const int64_t *sa_off, const int32_t *mapq, const int32_t *nm,
+                   const int32_t *qlen, int64_t *count, double *sum_e, double *sum_e2);
+
 /* Reachable CN segments of one amplicon interval — the traversal of ibg:369-384 with the read-name sets replayed natively.
  * visit_rows[n_visit]: rows of the chimeric table hashed to segments si..ei of chromosome `tid`, in the reference's visiting
  * order (segment ascending, then append order).  row_read/row_tid/cni0/cni1 are per table row, off[n_reads + 1] the row
