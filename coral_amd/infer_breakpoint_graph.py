@@ -382,15 +382,28 @@ class bam_to_breakpoint_nanopore():
         known = T.cni0 != -3
         rows = np.nonzero(known)[0]
         a, b = T.cni0[rows], T.cni1[rows]
-        e_row = np.concatenate([rows[a >= 0], rows[(b >= 0) & (b != a)]])
-        e_cni = np.concatenate([a[a >= 0], b[(b >= 0) & (b != a)]])
-        o = np.lexsort((e_row, e_cni, T.tid[e_row]))
-        self._e_row, self._e_cni = e_row[o], e_cni[o]
-        self._e_tid = T.tid[self._e_row]
+        # up to two entries per row, generated in row order (= the reference's append order inside every list) ...
+        ent_row = np.repeat(rows, 2)
+        ent_cni = np.stack([a, b], axis=1).ravel()
+        valid = np.stack([a >= 0, (b >= 0) & (b != a)], axis=1).ravel()
+        ent_row, ent_cni = ent_row[valid], ent_cni[valid]
+        ent_tid = T.tid[ent_row]
+        # ... then one STABLE sort by (chromosome, segment): a 16-bit key (segment ordinal over all chromosomes) sorts in O(n)
+        n_tid = len(chroms)
+        seg_count = np.zeros(n_tid + 1, dtype=np.int64)
+        for t, c in enumerate(chroms):
+            seg_count[t + 1] = len(self.cns_intervals_by_chr.get(c, ()))
+        seg_base = np.cumsum(seg_count)
+        if seg_base[-1] < 32768:
+            o = np.argsort((seg_base[ent_tid] + ent_cni).astype(np.int16), kind="stable")
+        else:
+            o = np.lexsort((ent_row, ent_cni, ent_tid))
+        self._e_row, self._e_cni, self._e_tid = ent_row[o], ent_cni[o], ent_tid[o]
         self._e_key = self._e_tid * (1 << 32) + self._e_cni
         kt = T.tid[rows]
-        ut, ft = np.unique(kt, return_index=True)
-        self._seg_tids = [int(t) for t in ut[np.argsort(ft, kind="stable")]]     # dict key order of ibg:201-202
+        present = np.nonzero(np.bincount(kt, minlength=n_tid))[0] if len(kt) else np.zeros(0, dtype=np.int64)
+        first_at = {int(t): int(np.argmax(kt == t)) for t in present}
+        self._seg_tids = sorted(first_at, key=first_at.get)                       # dict key order of ibg:201-202
         self.chimeric_alignments_seg = _SegIndexView(self)
 
     # ---- A5 ----------------------------------------------------------------------------------
