@@ -107,3 +107,29 @@ def test_pyobjects_extension_builds_the_reference_containers():
         P.read_tuples(names, ids.astype(np.int32), i, j)
     with pytest.raises(ValueError):
         P.read_tuples(names, ids, i[:2], j)
+
+
+def test_nm_stats_equals_sequential_python_sums():
+    """coral_nm_stats: the reference's `+=` loop over mapped, SA-less MAPQ-60 records (ibg:153-157), bit for bit."""
+    import ctypes as C
+    import numpy as np
+    from coral_amd import _lib
+    rng = np.random.default_rng(5)
+    n = 5000
+    tid = rng.integers(-1, 3, n).astype(np.int32)
+    mapq = rng.choice([0, 20, 60, 60, 60], n).astype(np.int32)
+    nm = rng.integers(0, 900, n).astype(np.int32)
+    qlen = rng.integers(500, 40000, n).astype(np.int32)
+    sa_cnt = (rng.random(n) < 0.2) * rng.integers(1, 4, n)
+    sa_off = np.concatenate([[0], np.cumsum(sa_cnt)]).astype(np.int64)
+    cnt, s0, s1 = C.c_int64(0), C.c_double(0), C.c_double(0)
+    assert _lib.lib().coral_nm_stats(n, tid.ctypes.data, sa_off.ctypes.data, mapq.ctypes.data, nm.ctypes.data, qlen.ctypes.data,
+                                     C.byref(cnt), C.byref(s0), C.byref(s1)) == 0
+    k, a, b = 0, 0.0, 0.0
+    for i in range(n):
+        if tid[i] >= 0 and sa_off[i + 1] == sa_off[i] and mapq[i] == 60:
+            e = int(nm[i]) / int(qlen[i])
+            a += e
+            b += e * e
+            k += 1
+    assert (cnt.value, s0.value, s1.value) == (k, a, b) and k > 1000
