@@ -369,13 +369,33 @@ class bam_to_breakpoint_nanopore():
         hi = np.maximum(T.ra, T.rb)
         T.cni0[:] = -3                     # -3: chromosome absent from the CN file -> set([-1]) (ibg:210)
         T.cni1[:] = -3
-        for t in np.unique(T.tid):
-            c = chroms[t]
-            if c not in self.cns_tree:
-                continue
-            m = T.tid == t
-            T.cni0[m] = self._pos2cni_many(c, lo[m])
-            T.cni1[m] = self._pos2cni_many(c, hi[m])
+        if all(v[4] for v in self.cns_tree.values()):
+            # every chromosome's segments are disjoint (the usual case): ONE binary search over all segments, keyed (tid, start)
+            parts = [(self._tid_of[c], v) for c, v in self.cns_tree.items() if c in self._tid_of]
+            has_tree = np.zeros(len(chroms) + 1, dtype=bool)
+            if parts:
+                g_tid = np.concatenate([np.full(len(v[3]), t, dtype=np.int64) for t, v in parts])
+                g_st = np.concatenate([v[0][v[3]] for _, v in parts]).astype(np.int64)
+                g_en = np.concatenate([v[1][v[3]] for _, v in parts]).astype(np.int64)
+                g_ix = np.concatenate([v[2][v[3]] for _, v in parts]).astype(np.int64)
+                o = np.argsort(g_tid * (1 << 32) + g_st, kind="stable")
+                g_tid, g_st, g_en, g_ix = g_tid[o], g_st[o], g_en[o], g_ix[o]
+                g_key = g_tid * (1 << 32) + g_st
+                has_tree[[t for t, _ in parts]] = True
+                known_row = has_tree[T.tid]
+                for dst, p in ((T.cni0, lo), (T.cni1, hi)):
+                    k = np.searchsorted(g_key, T.tid * (1 << 32) + p, side="right") - 1
+                    kk = np.clip(k, 0, len(g_key) - 1)
+                    ok = (k >= 0) & (g_tid[kk] == T.tid) & (p < g_en[kk])
+                    dst[:] = np.where(known_row, np.where(ok, g_ix[kk], -1), -3)
+        else:
+            for t in np.unique(T.tid):
+                c = chroms[t]
+                if c not in self.cns_tree:
+                    continue
+                m = T.tid == t
+                T.cni0[m] = self._pos2cni_many(c, lo[m])
+                T.cni1[m] = self._pos2cni_many(c, hi[m])
         self._hashed = True
         self.chimeric_alignments.invalidate()
         # inverted index (chr, cni) -> reads, in the reference's append order (read, then segment)
