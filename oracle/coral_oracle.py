@@ -438,8 +438,8 @@ def solve_cn(inv, lin, lg, A, max_iter=200):
     """minimise Σ inv/x + lin·x − lg·log x  s.t.  A x = 0, x > 0  (objective bg:546-556), from x = 1.
 
     Infeasible-start Newton on the full KKT system (the Hessian is diagonal and may have zero entries —
-    concordant edges without read support — so no Schur complement; A may be rank deficient, hence least
-    squares), float64, iterated until the Newton step is below 1e-13 relative.  This is NOT cvxopt's
+    concordant edges without read support — so no Schur complement; A may be rank deficient, in which case
+    the step comes from least squares), float64, iterated until the Newton step is below 1e-13 relative.  This is NOT cvxopt's
     algorithm; it returns the optimum cvxopt.solvers.cp approximates.
     """
     n, p = len(lin), A.shape[0]
@@ -455,7 +455,15 @@ def solve_cn(inv, lin, lg, A, max_iter=200):
     r = resid(x, nu)
     for _ in range(max_iter):
         K[np.arange(n), np.arange(n)] = lg / (x * x) + 2.0 * inv / (x ** 3)
-        step = np.linalg.lstsq(K, -r, rcond=None)[0]
+        # Exact LU solve when the KKT matrix is regular; least squares only when A is rank deficient.  (lstsq alone truncates
+        # small singular values of this badly scaled matrix — entries span 1e-4 .. 1e10 at 2 M reads — and the inexact Newton
+        # direction then stalls the line search at an infeasible point: seen at full config-3 size, tools/validate_full_size.py.)
+        try:
+            step = np.linalg.solve(K, -r)
+            if not np.all(np.isfinite(step)) or np.linalg.norm(K @ step + r) > 1e-8 * max(1.0, np.linalg.norm(r)):
+                raise np.linalg.LinAlgError            # (numerically) singular: dependent balance rows
+        except np.linalg.LinAlgError:
+            step = np.linalg.lstsq(K, -r, rcond=None)[0]
         dx, dnu = step[:n], step[n:]
         t = 1.0
         neg = dx < 0
