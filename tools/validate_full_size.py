@@ -1,7 +1,7 @@
 """One-off parity check at FULL config-3 size: product (HIP kernels + native host pieces + look-ahead threads) against the CPU
 oracle on the same 2 M reads.  Takes ~6 minutes of CPU for the oracle; run with PYTHONHASHSEED=0 for the strict text comparison.
 
-    PYTHONHASHSEED=0 python tools/validate_full_size.py [n_reads] > gpurun_out/full_size_parity.txt
+    PYTHONHASHSEED=0 python tools/validate_full_size.py [n_reads [config]] > gpurun_out/full_size_parity.txt
 """
 import os, sys, time, tempfile
 sys.path.insert(0, ".")
@@ -13,7 +13,8 @@ from oracle.hostrecords import HostRecords
 from tests.product_check import compare_graph_text
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000000
-cfg = synth.scaled_config("cfg3", n)
+name = sys.argv[2] if len(sys.argv) > 2 else "cfg3"
+cfg = synth.scaled_config(name, n)
 work = tempfile.mkdtemp()
 cn, seeds = os.path.join(work, "cn.bed"), os.path.join(work, "seeds.bed")
 synth.write_cn_bed(cfg, cn); synth.write_seed_bed(cfg, seeds)
@@ -38,6 +39,6 @@ for g, og in zip(b.lr_graph, ob.lr_graph):
         assert [e[:6] for e in g.discordant_edges] == [e[:6] for e in og.discordant_edges]      # the set-order dependent edge order
         compare_graph_text(graph_text(g), O.graph_text(og))
         assert b.new_bp_stats == ob.new_bp_stats
-print("PARITY OK at %d reads: sequence / concordant / discordant edges, supports and read sets identical%s" % (
+print("PARITY OK (" + name + ") at %d reads: sequence / concordant / discordant edges, supports and read sets identical%s" % (
     n, "; discordant-edge ORDER, breakpoint statistics and graph text identical (CN within 1e-6)" if strict else ""))
 print("speed-up of this run: %.0fx (oracle %.1fs vs product %.2fs, first product call incl. warm-up)" % (to / tg, to, tg))
