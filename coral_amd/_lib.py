@@ -94,3 +94,53 @@ def lib():
 def check(rc: int, what: str):
     if rc != 0:
         raise CoralHipError("%s failed (%d): %s" % (what, rc, lib().coral_last_error().decode()))
+
+
+_pyset_checked = False
+
+
+def check_pyset_replay():
+    """The native replay of the interpreter's ``set`` (coral_pyset_* / coral_reach_*) reproduces CPython's table growth and
+    probing rules; another interpreter (or a future CPython with a different set) would silently give a different — still
+    valid, but not reference-identical — discordant-edge order.  So the replay is checked once per process against real sets
+    of str on a few hundred seeded operations, and a mismatch is an error, not a fallback."""
+    global _pyset_checked
+    if _pyset_checked:
+        return
+    import random
+    import numpy as np
+    L = lib()
+    rnd = random.Random(12345)
+    names = ["read%07d_%d" % (rnd.randrange(10 ** 7), k) for k in range(900)]
+    hashes = np.array([hash(nm) for nm in names], dtype=np.int64)
+    n_keys = 7
+    entries = [(rnd.randrange(n_keys), rnd.randrange(len(names))) for _ in range(2500)]
+    key = np.array([k for k, _ in entries], dtype=np.int32)
+    item = np.array([i for _, i in entries], dtype=np.int32)
+    counts = np.zeros(n_keys, dtype=np.int32)
+    h = L.coral_pyset_batch_create(len(entries), key.ctypes.data, item.ctypes.data, hashes.ctypes.data, n_keys, counts.ctypes.data)
+    if not h:
+        raise CoralHipError("coral_pyset_batch_create failed")
+    try:
+        sets = {}
+        for k, i in entries:
+            if k in sets:
+                sets[k].add(names[i])
+            else:
+                sets[k] = set([names[i]])
+        index = {nm: i for i, nm in enumerate(names)}
+        for trial in range(6):
+            ks = [rnd.randrange(n_keys) for _ in range(rnd.randrange(1, 5))]
+            acc = set([])
+            for k in ks:
+                acc |= sets.get(k, set())
+            uk = np.array(ks, dtype=np.int32)
+            out = np.empty(len(names) + 1, dtype=np.int32)
+            n = C.c_int32(0)
+            check(L.coral_pyset_union_order(h, len(uk), uk.ctypes.data, out.ctypes.data, C.byref(n)), "coral_pyset_union_order")
+            if out[:n.value].tolist() != [index[nm] for nm in acc] or [int(c) for c in counts] != [len(sets.get(k, ())) for k in range(n_keys)]:
+                raise CoralHipError("the native replay of this interpreter's set iteration order does not match real sets "
+                                    "(libcoral_hip replays CPython 3.10-3.12 sets); refusing to emit edges in a different order")
+    finally:
+        L.coral_pyset_batch_free(h)
+    _pyset_checked = True

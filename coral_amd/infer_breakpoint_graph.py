@@ -441,6 +441,7 @@ class bam_to_breakpoint_nanopore():
             if self.pos2cni(c, by[c][rcni][2] + self.interval_delta):
                 iv[2] = by[c][rcni][2] + self.interval_delta
         ccid = 0
+        _lib.check_pyset_replay()            # once per process: the set replay must match this interpreter's sets
         # look-ahead worker for the pure part of every search step (_prepare_step); results are keyed by interval index and
         # coordinates, so a step is recomputed in line if its interval changed after it was queued (it never does today)
         self._ahead = {}
