@@ -42,51 +42,58 @@ class HsrResult:
         self.points: List[list] = []
 
 
+def _merge_walk(segments, walk):
+    """Segments of one cycle / path in walk order, neighbours that continue each other on the same strand fused into one
+    interval, and the last one folded into the first when the walk closes on itself (cycle2bed.py:29-48)."""
+    out = []
+    for token in walk:
+        sid, strand = token[:-1], token[-1]
+        if int(sid) <= 0:                        # segment 0 marks the ends of a linear path
+            continue
+        chrom, start, end = segments[sid]
+        last = out[-1] if out else None
+        if last and last[3] == strand == '+' and last[0] == chrom and last[2] + 1 == start:
+            last[2] = end
+        elif last and last[3] == strand == '-' and last[0] == chrom and last[1] - 1 == end:
+            last[1] = start
+        else:
+            out.append([chrom, start, end, strand])
+    head, tail = out[0], out[-1]
+    if head[3] == '+' and tail[0] == head[0]:
+        if tail[3] == '+' and tail[2] + 1 == head[1]:
+            head[1] = tail[1]
+            out.pop()
+    head, tail = out[0], out[-1]
+    if head[3] == '+' and tail[0] == head[0]:
+        if tail[3] == '-' and tail[1] - 1 == head[2]:
+            head[2] = tail[2]
+            out.pop()
+    return out
+
+
 def convert_cycles_to_bed(cycle_fn, output_fn):
-    """AmpliconSuite ``*_cycles.txt`` -> bed (cycle2bed.py:7-73 with its default arguments, as hsr.py:65 calls it)."""
-    all_segs, cycles = {}, {}
+    """AmpliconSuite ``*_cycles.txt`` -> bed, what cycle2bed.convert_cycles_to_bed does with its default arguments (the call
+    of hsr.py:65): ``Segment`` lines define numbered intervals, every ``Cycle=..;Copy_count=..;Segments=..`` line a walk."""
+    segments, walks = {}, {}
     with open(cycle_fn) as fp:
         for line in fp:
             t = line.strip().split()
             if not t:
                 continue
             if t[0] == "Segment":
-                all_segs[t[1]] = [t[2], int(t[3]), int(t[4])]
-            if t[0][:5] == "Cycle":
-                cycle_id, weight, segs = 1, 1.0, ['0+', '0-']
-                for s in t[0].split(';'):
-                    s = s.split('=')
-                    if s[0] == "Cycle":
-                        cycle_id = s[1]
-                    if s[0] == "Copy_count":
-                        weight = float(s[1])
-                    if s[0] == "Segments":
-                        segs = s[1].split(',')
-                iscyclic = (segs[0] != "0+" or segs[-1] != "0-")
-                cycle = []
-                for seg in segs:
-                    sid, sdir = seg[:-1], seg[-1]
-                    if int(sid) > 0:
-                        cur = all_segs[sid]
-                        if cycle and cycle[-1][-1] == '+' and sdir == '+' and cycle[-1][0] == cur[0] and cycle[-1][2] + 1 == cur[1]:
-                            cycle[-1][2] = cur[2]
-                        elif cycle and cycle[-1][-1] == '-' and sdir == '-' and cycle[-1][0] == cur[0] and cycle[-1][1] - 1 == cur[2]:
-                            cycle[-1][1] = cur[1]
-                        else:
-                            cycle.append(cur + [sdir])
-                if cycle[-1][-1] == '+' and cycle[0][-1] == '+' and cycle[-1][0] == cycle[0][0] and cycle[-1][2] + 1 == cycle[0][1]:
-                    cycle[0][1] = cycle[-1][1]
-                    del cycle[-1]
-                if cycle[-1][-1] == '-' and cycle[0][-1] == '+' and cycle[-1][0] == cycle[0][0] and cycle[-1][1] - 1 == cycle[0][2]:
-                    cycle[0][2] = cycle[-1][2]
-                    del cycle[-1]
-                cycles[int(cycle_id)] = [iscyclic, weight, cycle]
+                segments[t[1]] = (t[2], int(t[3]), int(t[4]))
+            if t[0].startswith("Cycle"):
+                fields = dict(kv.split('=', 1) for kv in t[0].split(';') if '=' in kv)
+                walk = fields.get("Segments", "0+,0-").split(',')
+                cyclic = walk[0] != "0+" or walk[-1] != "0-"
+                walks[int(fields.get("Cycle", 1))] = (cyclic, float(fields.get("Copy_count", 1.0)), _merge_walk(segments, walk))
     print("Creating bed-converted cycles file: " + output_fn)
     with open(output_fn, 'w') as fp:
         fp.write("#chr\tstart\tend\torientation\tcycle_id\tiscyclic\tweight\n")
-        for i in range(1, len(cycles) + 1):
-            for seg in cycles[i][2]:
-                fp.write("%s\t%d\t%d\t%s\t%d\t%s\t%f\n" % (seg[0], seg[1], seg[2], seg[3], i, cycles[i][0], cycles[i][1]))
+        for cid in range(1, len(walks) + 1):
+            cyclic, weight, intervals = walks[cid]
+            for chrom, start, end, strand in intervals:
+                fp.write("%s\t%d\t%d\t%s\t%d\t%s\t%f\n" % (chrom, start, end, strand, cid, cyclic, weight))
 
 
 def junction_candidates(T: ChimericTable, ecdna, chroms, chr_rank) -> Candidates:
@@ -164,6 +171,55 @@ def _candidate_lists(c: Candidates, chroms, names) -> List[list]:
     return out
 
 
+def _ecdna_intervals(args):
+    """Intervals of the ecDNA from a cycles bed (or an AmpliconSuite ``*_cycles.txt``, converted first) — hsr.py:59-79."""
+    path = args.cycles
+    if path.endswith("_cycles.txt"):
+        sep = "" if args.output_prefix.endswith("/") else "_"
+        bed = "%s%sconverted_cycles.bed" % (args.output_prefix, sep)
+        convert_cycles_to_bed(path, bed)
+        path = bed
+    elif not path.endswith(".bed"):
+        sys.stderr.write(args.cycles + "\n")
+        sys.stderr.write("Cycles file must be either a valid *_cycles.txt file or a converted .bed file!\n")
+        sys.exit(1)
+    with open(path) as fp:
+        rows = [ln.split() for ln in fp if not ln.startswith("#")]
+    return [[r[0], int(r[1]), int(r[2])] for r in rows if len(r) >= 3]
+
+
+def _copy_numbers(cn_seg):
+    """{chromosome: [[start, end, cn], ...]} from a CNVkit ``.cns`` (cn = 2 * 2**log2) or a ``.bed`` (4th column) — hsr.py:84-108."""
+    per_chrom = {}
+    with open(cn_seg) as fp:
+        for ln in fp:
+            if ln.startswith('chromosome'):
+                continue
+            f = ln.strip().split()
+            if cn_seg.endswith(".cns"):
+                cn = 2 * (2 ** float(f[4]))
+            elif cn_seg.endswith(".bed"):
+                cn = float(f[3])
+            else:
+                sys.stderr.write(cn_seg + "\n")
+                sys.stderr.write("Invalid cn_seg file format!\n")
+            per_chrom.setdefault(f[0], []).append([int(f[1]), int(f[2]), cn])
+    return per_chrom
+
+
+def _genome_axis():
+    """Start of every chromosome and the tick positions on a 0-100 axis over the concatenated genome (hsr.py:173-183)."""
+    total = sum(chr_sizes.values())
+    start, ticks, borders, run = {}, [], [], 0
+    for c, size in chr_sizes.items():
+        start[c] = run * 100.0 / total
+        run += size
+        ticks.append((run - 0.5 * size) * 100.0 / total)
+        if run < total:
+            borders.append(run * 100.0 / total)
+    return total, start, ticks, borders
+
+
 def locate_hsrs(args, records=None, device="cuda:0"):
     """hsr.locate_hsrs(args) (hsr.py:54-224).  ``records``: already decoded ``DeviceRecords`` (tests, pipelines)."""
     import matplotlib as mpl
@@ -176,42 +232,13 @@ def locate_hsrs(args, records=None, device="cuda:0"):
     mpl.rc('ytick', labelsize=25)
 
     res = HsrResult()
-    ecdna, ecdna_ext = [], []
-    cycle_fn = args.cycles
-    if args.cycles.endswith("_cycles.txt"):
-        init_char = "" if args.output_prefix.endswith("/") else "_"
-        conv = args.output_prefix + init_char + "converted_" + "cycles.bed"
-        convert_cycles_to_bed(args.cycles, conv)
-        cycle_fn = conv
-    elif not args.cycles.endswith(".bed"):
-        sys.stderr.write(args.cycles + "\n")
-        sys.stderr.write("Cycles file must be either a valid *_cycles.txt file or a converted .bed file!\n")
-        sys.exit(1)
-    with open(cycle_fn, 'r') as fp:
-        for line in fp:
-            if line.startswith("#"):
-                continue
-            s = line.strip().split()
-            ecdna.append([s[0], int(s[1]), int(s[2])])
-            ecdna_ext.append([s[0], int(s[1]) - args.bp_match_cutoff, int(s[2]) + args.bp_match_cutoff])
+    cutoff = args.bp_match_cutoff
+    ecdna = _ecdna_intervals(args)
+    padded = [(c, s - cutoff, e + cutoff) for c, s, e in ecdna]
     print("ecDNA intervals:")
-    for ival in ecdna:
-        print(ival)
-
-    cns_dict = {}
-    with open(args.cn_seg, 'r') as fp:
-        for line in fp:
-            s = line.strip().split()
-            if line.startswith('chromosome'):
-                continue
-            if args.cn_seg.endswith(".cns"):
-                cn = 2 * (2 ** float(s[4]))
-            elif args.cn_seg.endswith(".bed"):
-                cn = float(s[3])
-            else:
-                sys.stderr.write(args.cn_seg + "\n")
-                sys.stderr.write("Invalid cn_seg file format!\n")
-            cns_dict.setdefault(s[0], []).append([int(s[1]), int(s[2]), cn])
+    for iv in ecdna:
+        print(iv)
+    cns = _copy_numbers(args.cn_seg)
 
     if records is None:
         from .bam import decode_bam
@@ -225,69 +252,56 @@ def locate_hsrs(args, records=None, device="cuda:0"):
     cands = junction_candidates(T, ecdna, chroms, chr_rank)
     res.candidates = _candidate_lists(cands, chroms, names)
 
-    thr = float(args.normal_cov) * 0.5
-    sizes, calls = call_breakpoints(cands, thr, args.bp_match_cutoff_clustering, args.bp_match_cutoff, thr, False)
-    res.cluster_sizes = sizes
+    # clusters -> exact breakpoints -> merged list (hsr.py:149-170); a sub-cluster counts when its distinct support reaches
+    # half the normal coverage, which is also the minimum cluster size
+    need = float(args.normal_cov) * 0.5
+    res.cluster_sizes, calls = call_breakpoints(cands, need, args.bp_match_cutoff_clustering, cutoff, need, False)
     for head, p1, p2, sup, st in calls:
         bp = [chroms[cands.c1[head]], p1, _ORI[cands.o1[head]], chroms[cands.c2[head]], p2, _ORI[cands.o2[head]],
               (names[cands.read[head]], int(cands.i[head]), int(cands.j[head])), int(cands.gap[head]), int(cands.swapped[head])]
-        bpr = [(names[cands.read[k]], int(cands.i[k]), int(cands.j[k])) for k in sup.tolist()]
-        res.calls.append([bp, bpr, st])
-        hit = -1
-        for k, old in enumerate(res.bp_refined):
-            if bp[0] == old[0] and bp[3] == old[3] and bp[2] == old[2] and bp[5] == old[5] and \
-                    abs(bp[1] - old[1]) <= args.bp_match_cutoff and abs(bp[4] - old[4]) < args.bp_match_cutoff:
-                old[-1] |= set(bpr)
-                hit = k
-                break
-        if hit < 0:
-            res.bp_refined.append(bp + [bpr])
+        support = [(names[cands.read[k]], int(cands.i[k]), int(cands.j[k])) for k in sup.tolist()]
+        res.calls.append([bp, support, st])
+        same = [old for old in res.bp_refined
+                if (old[0], old[2], old[3], old[5]) == (bp[0], bp[2], bp[3], bp[5])
+                and abs(bp[1] - old[1]) <= cutoff and abs(bp[4] - old[4]) < cutoff]
+        if same:
+            same[0][-1] |= set(support)                       # merged into the FIRST close breakpoint (hsr.py:160-165)
+        else:
+            res.bp_refined.append(bp + [support])
             res.bp_stats.append(st)
     print("Found %d breakpoints connecting ecDNA and chromosomes." % len(res.bp_refined))
 
-    sum_sizes = sum(chr_sizes.values())
-    agg_size = 0
-    xtick_pos, starting_pos = [], {}
-    for c in chr_sizes.keys():
-        agg_size += chr_sizes[c]
-        if agg_size < sum_sizes:
-            plt.plot([agg_size * 100.0 / sum_sizes, agg_size * 100.0 / sum_sizes], [-1, 1000000], 'k--', linewidth=2)
-        xtick_pos.append((agg_size - 0.5 * chr_sizes[c]) * 100.0 / sum_sizes)
-        starting_pos[c] = (agg_size - chr_sizes[c]) * 100.0 / sum_sizes
+    total, start_of, ticks, borders = _genome_axis()
+    for x in borders:
+        plt.plot([x, x], [-1, 1000000], 'k--', linewidth=2)
 
-    def on_ecdna(c, p):
-        return any(c == iv[0] and p <= iv[2] and iv[1] <= p for iv in ecdna_ext)       # interval_overlap_l([c, p, p], ...) >= 0
+    def touches_ecdna(c, p):                                  # interval_overlap_l([c, p, p], padded intervals) >= 0
+        return any(c == ic and lo <= p <= hi for ic, lo, hi in padded)
 
+    limit = float(args.normal_cov) * 2.5
     for bp in res.bp_refined:
-        on1, on2 = on_ecdna(bp[0], bp[1]), on_ecdna(bp[3], bp[4])
-        if on1 and not on2:
-            c, p = bp[3], bp[4]
-        elif on2 and not on1:
-            c, p = bp[0], bp[1]
-        else:
+        first, second = touches_ecdna(bp[0], bp[1]), touches_ecdna(bp[3], bp[4])
+        if first == second:
+            continue                                          # both ends on the ecDNA, or neither
+        c, p = (bp[3], bp[4]) if first else (bp[0], bp[1])    # the chromosomal end
+        if c not in start_of:
             continue
-        if c in starting_pos.keys():
-            cn = 0.0
-            for seg in cns_dict[c]:                           # KeyError for a chromosome without CN rows, as the reference
-                if p > seg[0] and p < seg[1]:
-                    cn = seg[2]
-                    break
-            if cn <= 5.0 and len(bp[-1]) <= float(args.normal_cov) * 2.5:
-                print("Breakpoint", bp[:6], "Support = ", len(bp[-1]))
-                xpos = starting_pos[c] + p * 100.0 / sum_sizes
-                ypos = len(bp[-1])
-                res.points.append([xpos, ypos])
-                plt.plot(xpos, ypos, 'bo')
+        cn = next((seg[2] for seg in cns[c] if seg[0] < p < seg[1]), 0.0)     # KeyError without CN rows, as the reference
+        support = len(bp[-1])
+        if cn <= 5.0 and support <= limit:
+            print("Breakpoint", bp[:6], "Support = ", support)
+            res.points.append([start_of[c] + p * 100.0 / total, support])
+            plt.plot(res.points[-1][0], support, 'bo')
 
     plt.xlim([0, 100])
     plt.ylim([1, 500])
     plt.yscale('log')
-    plt.xticks(xtick_pos, list(range(1, 23)) + ['X', 'Y'])
+    plt.xticks(ticks, list(range(1, 23)) + ['X', 'Y'])
     plt.title(args.output_prefix + " integration loci", fontsize=25)
     plt.ylabel('Long read support', fontsize=25)
     plt.tight_layout()
-    out_img_name = "integration_sites_" + args.output_prefix
-    plt.savefig(out_img_name + '.png')
+    image = "integration_sites_" + args.output_prefix + ".png"
+    plt.savefig(image)
     plt.close()
-    print('\nCreated ' + out_img_name + '.png')
+    print('\nCreated ' + image)
     return res

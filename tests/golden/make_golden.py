@@ -219,6 +219,42 @@ def hsr_only():
         subprocess.run(cmd, cwd=ROOT, env=env, check=True, stdout=subprocess.DEVNULL)
 
 
+CYCLES_EXAMPLE = """List of cycle segments
+Interval\t1\tchr8\t127000000\t129000000
+Interval\t2\tchr12\t50000000\t51000000
+Segment\t1\tchr8\t127000000\t127499999
+Segment\t2\tchr8\t127500000\t127999999
+Segment\t3\tchr8\t128400000\t128899999
+Segment\t4\tchr12\t50100000\t50299999
+Segment\t5\tchr12\t50300000\t50499999
+Segment\t6\tchr8\t126000000\t126999999
+Cycle=1;Copy_count=12.5;Segments=1+,2+,4-,3+
+Cycle=2;Copy_count=3.25;Segments=0+,5-,4-,3+,0-
+Cycle=3;Copy_count=2.0;Segments=2+,3-,6+,1+
+Cycle=4;Copy_count=1.0;Segments=2-,1-,5+
+Cycle=5;Copy_count=7.0;Segments=1+,4+,2-
+"""
+
+
+def cycles_only():
+    """cycles_example.json: a hand-written AmpliconSuite cycles file and the bed the reference's cycle2bed makes of it
+    (hsr.py:61-66 converts *_cycles.txt inputs this way)."""
+    import contextlib
+    import io
+    import tempfile
+    sys.path.insert(0, REF_SRC)
+    import cycle2bed
+    d = tempfile.mkdtemp()
+    a, b = os.path.join(d, "x_cycles.txt"), os.path.join(d, "x.bed")
+    with open(a, "w") as fp:
+        fp.write(CYCLES_EXAMPLE)
+    with contextlib.redirect_stdout(io.StringIO()):
+        cycle2bed.convert_cycles_to_bed(a, b)
+    with open(os.path.join(HERE, "cycles_example.json"), "w") as fp:
+        json.dump({"cycles_txt": CYCLES_EXAMPLE, "bed": open(b).read(),
+                   "made_by": "cycle2bed.convert_cycles_to_bed(cycle_fn, output_fn) of the reference, default arguments"}, fp, indent=1)
+
+
 def plotcov_only():
     for cfg, region in PLOTCOV_CASES:
         out = os.path.join(HERE, "plotcov_%s%s.json" % (cfg, "_region" if region else ""))
@@ -232,6 +268,9 @@ if __name__ == "__main__":
         hsr_only()
     elif sys.argv[1:] == ["plotcov"]:
         plotcov_only()
+    elif sys.argv[1:] == ["cycles"]:
+        cycles_only()
     else:
         main()
         plotcov_only()
+        cycles_only()

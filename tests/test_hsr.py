@@ -106,3 +106,16 @@ def test_product_on_gpu_matches_reference(case, cov, golden_dir, tmp_path, monke
     from coral_amd.records import DeviceRecords
     gold, cfg, rec, ecdna, cn, cyc = _load(golden_dir, case, cov, tmp_path)
     _check_product(hsr, DeviceRecords(rec, "cuda:0"), gold, cn, cyc, cov, tmp_path, monkeypatch)
+
+
+def test_cycles_txt_conversion_matches_reference(golden_dir, tmp_path, capsys):
+    """*_cycles.txt -> bed (what hsr.py:61-66 does through cycle2bed): fused neighbours, closing of cyclic walks, paths."""
+    from coral_amd import hsr
+    with open(os.path.join(golden_dir, "cycles_example.json")) as fp:
+        gold = json.load(fp)
+    src, dst = str(tmp_path / "x_cycles.txt"), str(tmp_path / "x.bed")
+    with open(src, "w") as fp:
+        fp.write(gold["cycles_txt"])
+    hsr.convert_cycles_to_bed(src, dst)
+    assert open(dst).read() == gold["bed"]
+    assert capsys.readouterr().out == "Creating bed-converted cycles file: " + dst + "\n"
