@@ -502,7 +502,7 @@ extern "C" int coral_time_stream_read(const uint32_t *cigar, long long n_words, 
 
 static int g_scan_variant = 15;  // 8 KiB per wave in flight + conservative gap filter + tiles of 8 consecutive records per wave: best launch time (profiles/r01_scan_variants.md)
 extern "C" int coral_set_scan_variant(int v) {
-    if (v < 1 || v > 24) return CORAL_ERR_ARG;
+    if (v < 1 || v > 27) return CORAL_ERR_ARG;
     g_scan_variant = v;
     return CORAL_OK;
 }
@@ -606,6 +606,12 @@ extern "C" int coral_cigar_scan(const coral_records_t *rec, int32_t min_gap, int
         hipLaunchKernelGGL((k_cigar_scan_v2<4, true, true, 8, true>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
                            (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
                            (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
+    else if (g_scan_variant == 25)
+        LAUNCH_TILED(4, false, 8);
+    else if (g_scan_variant == 26)
+        LAUNCH_TILED(2, false, 8);
+    else if (g_scan_variant == 27)
+        LAUNCH_TILED(16, false, 8);
     else if (g_scan_variant == 17)
         LAUNCH_TILED(8, false, 4);
     else if (g_scan_variant == 18)

@@ -176,7 +176,8 @@ int coral_time_cigar_scan(const coral_records_t *rec, int32_t min_gap, int32_t m
  * with 4 / 8 (default) / 2 KiB per wave in flight; 5 = diagnostic (loads only, no arithmetic, outputs invalid);
  * 6 = "flat" kernel (each wave streams a contiguous range of whole records); 7 = variant 3 with a conservative per-chunk
  * filter in front of the exact gap search; 8-14 = packed / in-place-ring experiments; 15 (default) / 16 / 17 / 18 = variant 7
- * with tiles of 8 / 32 / 4 / 16 consecutive records per wave; 19 = tiled diagnostic (loads only).  coral_time_stream_read times a plain
+ * with tiles of 8 / 32 / 4 / 16 consecutive records per wave; 19 = tiled diagnostic (loads only); 20-27 = further
+ * measured alternatives (tile stream, unmasked full-chunk loads, other batch sizes; profiles/r01_scan_variants.md).  coral_time_stream_read times a plain
  * grid-stride 16-byte-per-lane read of n_words uint32 (the ceiling for a kernel that touches every op once). */
 int coral_set_scan_variant(int variant);
 int coral_set_probe_mode(int mode);   /* 1 = grid-stride probe, 2 = one contiguous region per wave */

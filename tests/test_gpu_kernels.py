@@ -79,7 +79,7 @@ def case(request):
     return request.param, rec, HostRecords(rec), DeviceRecords(rec, "cuda:0")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 21, 22, 23])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 21, 22, 23, 25, 26, 27])
 def test_cigar_scan(case, variant):
     """Every variant of the scan kernel (first version, batched per-record 2/4/8 KiB, flat contiguous ranges, and the
     8 KiB one with the conservative per-chunk gap filter)."""

@@ -21,7 +21,7 @@ import numpy as np
 assert torch.equal(r1.mbases, res.mbases) and torch.equal(r1.qinfer, res.qinfer) and torch.equal(r1.blk_first, res.blk_first) and torch.equal(r1.blk_last, res.blk_last) and np.array_equal(r1.gaps, res.gaps), "variants disagree"
 assert L0.coral_set_scan_variant(7) == 0; r7 = kernels.cigar_scan(dr)
 assert torch.equal(r7.mbases, res.mbases) and torch.equal(r7.qinfer, res.qinfer) and torch.equal(r7.blk_first, res.blk_first) and torch.equal(r7.blk_last, res.blk_last) and np.array_equal(r7.gaps, res.gaps), "filtered variant disagrees"
-for v in (15, 23):
+for v in (15, 25, 26, 27):
     assert L0.coral_set_scan_variant(v) == 0; r8 = kernels.cigar_scan(dr)
     assert torch.equal(r8.mbases, res.mbases) and torch.equal(r8.qinfer, res.qinfer) and torch.equal(r8.blk_first, res.blk_first) and torch.equal(r8.blk_last, res.blk_last) and np.array_equal(r8.gaps, res.gaps), "packed variant disagrees"
 L0.coral_set_scan_variant(6); r6 = kernels.cigar_scan(dr)
@@ -32,7 +32,7 @@ rs = dr.c_struct()
 mb = torch.empty(dr.n, dtype=torch.int32, device="cuda"); qi = torch.empty_like(mb); b0 = torch.empty_like(mb); b1 = torch.empty_like(mb)
 gaps = torch.empty((1 << 20, 4), dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
 ms = C.c_float(0)
-VARIANTS = [15, 19, 23, 24]
+VARIANTS = [15, 25, 26, 27]
 for it in range(3 * len(VARIANTS)):
     L.coral_set_scan_variant(VARIANTS[it % len(VARIANTS)])
     _lib.check(L.coral_time_cigar_scan(C.byref(rs), 600, 20, mb.data_ptr(), qi.data_ptr(), b0.data_ptr(), b1.data_ptr(), gaps.data_ptr(), cnt.data_ptr(), 1 << 20, 10, C.byref(ms), dr.stream()), "time")
