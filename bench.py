@@ -62,7 +62,6 @@ def main():
 
     from coral_amd import synth, kernels
     from coral_amd import infer_breakpoint_graph as ibg
-    from coral_amd.records import DeviceRecords
     from coral_amd import sharding
 
     if a.scan_variant:

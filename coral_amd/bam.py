@@ -11,7 +11,7 @@ import ctypes as C
 import os
 import struct
 import zlib
-from typing import List, Optional
+from typing import Optional
 
 import numpy as np
 import torch

@@ -10,7 +10,7 @@ first-seen ordering downstream is identical.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Sequence, Tuple
 
 import numpy as np
 

@@ -25,7 +25,7 @@ import math
 import sys
 import time
 from operator import itemgetter
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, Optional
 
 import numpy as np
 
@@ -36,10 +36,9 @@ from concurrent.futures import ThreadPoolExecutor
 
 from . import _lib, global_names, kernels
 from . import _pyobjects          # CPython extension built by __graft_entry__.build(); no Python fallback
-from .bpcluster import call_breakpoints, bpc2bp, cluster_bp_list
-from .breakpoint_graph import (BreakpointGraph, breakpoint_info_text, compute_cn_lr, graph_text,
-                               output_breakpoint_graph_lr, output_breakpoint_info_lr)
-from .chimeric import (Candidates, ChimericTable, build_chimeric_table, candidates_between, candidates_within)
+from .bpcluster import call_breakpoints
+from .breakpoint_graph import BreakpointGraph, compute_cn_lr, output_breakpoint_graph_lr, output_breakpoint_info_lr
+from .chimeric import Candidates, ChimericTable, build_chimeric_table, candidates_within
 from .global_names import chr_idx
 
 _ORI = "+-"

@@ -12,7 +12,6 @@ binary searches over the sorted sequence edges and every distinct pair is walked
 """
 from __future__ import annotations
 
-from typing import Dict, List, Sequence, Tuple
 
 import numpy as np
 

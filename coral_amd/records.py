@@ -4,7 +4,6 @@ PyTorch is used for device memory and streams only (plumbing); the kernels are i
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import List, Optional
 
 import numpy as np

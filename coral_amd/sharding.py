@@ -11,7 +11,6 @@ tests, "gloo".
 """
 from __future__ import annotations
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

@@ -1,5 +1,5 @@
 """cProfile of one step, callee breakdown of the phases outside the interval search."""
-import cProfile, pstats, sys, os, time, tempfile, io
+import cProfile, pstats, sys, os, tempfile, io
 sys.path.insert(0, ".")
 import torch
 from coral_amd import synth, sharding
