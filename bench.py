@@ -178,8 +178,8 @@ def cpu_baseline(config, n_sample, work):
     O.reconstruct_graph(host, seeds, cn, os.path.join(work, "cpu"))
     dt = time.perf_counter() - t0
     return {"value": n_sample / dt, "unit": "reads/s", "cores": 1, "kind": "port",
-            "sample": "first %d reads of %s (same generator and seed), decoded records in host memory -> graph files, %.1f s"
-                      % (n_sample, config, dt)}
+            "sample": "first %d reads of %s (same generator and seed), decoded records in host memory -> graph files, %.1f s; "
+                      "single-threaded like the reference (host has %d cores)" % (n_sample, config, dt, os.cpu_count() or 0)}
 
 
 if __name__ == "__main__":
