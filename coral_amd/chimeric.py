@@ -65,15 +65,15 @@ def build_chimeric_table(dr) -> ChimericTable:
                                          dr.h_nm.ctypes.data, dr.h_qlen.ctypes.data, C.byref(cnt), C.byref(s0), C.byref(s1)),
                "coral_nm_stats")
     T.n_mapq60_plain, T.nm_sum, T.nm_sum_sq = int(cnt.value), float(s0.value), float(s1.value)
-    rows, off, name_id, failed, rl = kernels.sa_table(dr)
+    cols, off, name_id, failed, rl = kernels.sa_table(dr)
     T.read_length = rl
     T.name_id, T.failed, T.off = name_id, failed, off
-    r64 = rows.astype(np.int64)
-    T.qs, T.qe, T.tid, T.ra, T.rb, T.strand, T.mapq = (np.ascontiguousarray(r64[:, k]) for k in range(7))
+    T.qs, T.qe, T.tid, T.ra, T.rb, T.strand, T.mapq = (cols[k] for k in range(7))
+    n_rows = cols.shape[1]
     T.read = np.repeat(np.arange(len(name_id), dtype=np.int64), np.diff(off))
-    T.nm = r64[:, 7].astype(np.float64) / (T.qe - T.qs) if len(r64) else np.zeros(0)
-    T.cni0 = np.full(len(r64), -1, dtype=np.int64)
-    T.cni1 = np.full(len(r64), -1, dtype=np.int64)
+    T.nm = cols[7].astype(np.float64) / (T.qe - T.qs) if n_rows else np.zeros(0)
+    T.cni0 = np.full(n_rows, -1, dtype=np.int64)
+    T.cni1 = np.full(n_rows, -1, dtype=np.int64)
     return T
 
 

@@ -297,10 +297,15 @@ def _sa_table_local(dr):
     if rc != 0:
         raise _lib.CoralHipError("coral_sa_table failed (%d): %s" % (rc, L.coral_sa_last_error().decode()))
     n_reads, n_rows = int(counts[0]), int(counts[1])
-    return (out_rows[:n_rows].cpu().numpy(), out_off[:n_reads + 1].cpu().numpy().astype(np.int64),
+    # the rows leave the GPU column by column (transposed there): the host wants seven contiguous int64 columns, and cutting
+    # them out of a row-major [n, 8] array costs more than the whole kernel
+    cols = out_rows[:n_rows].t().contiguous().to(torch.int64).cpu().numpy()
+    return (cols, out_off[:n_reads + 1].cpu().numpy().astype(np.int64),
             out_name[:n_reads].cpu().numpy().astype(np.int64), out_failed[:n_reads].cpu().numpy().astype(bool),
             out_rl[:dr.n_names].cpu().numpy().astype(np.int64))
 
 
 def sa_table(dr):
+    """(columns int64 [8, n_rows] = qs, qe, tid, ra, rb, strand, mapq, nm; row offsets per read; name id per read; failed flag
+    per read; read length per name id) — coral_sa_table over all SA rows."""
     return _sa_table_local(dr)

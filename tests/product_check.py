@@ -223,7 +223,8 @@ def install_cpu_kernel_fakes(monkeypatch):
         rl = np.full(len(h.names), -1, dtype=np.int64)
         for rn, v in ob.read_length.items():
             rl[name_id_of[rn]] = v
-        return (np.array(rows, dtype=np.int32).reshape(-1, 8), np.array(off, dtype=np.int64), np.array(names, dtype=np.int64),
+        cols = np.ascontiguousarray(np.array(rows, dtype=np.int64).reshape(-1, 8).T)          # [8, n_rows], as the product's wrapper
+        return (cols, np.array(off, dtype=np.int64), np.array(names, dtype=np.int64),
                 np.array(failed, dtype=bool), rl)
 
     monkeypatch.setattr(kernels, "_sa_table_local", sa_table_local)
