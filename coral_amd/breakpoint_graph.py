@@ -17,6 +17,9 @@ reference's own BreakpointGraph class (with its cycle-step helpers) as the conta
 """
 from __future__ import annotations
 
+import math
+import warnings
+
 import numpy as np
 
 from .global_names import chr_idx
@@ -44,6 +47,8 @@ class BreakpointGraph:
             raise Exception("Breakpoint node must be of form (chr, pos, orientation).")
         if node_ not in self.endnodes:
             self.endnodes[node_] = []
+        else:
+            warnings.warn("Node corresponding to interval end already exists.")
 
     # -- edges ---------------------------------------------------------------------------------
     def add_sequence_edge(self, chr, l, r, sr_count=-1, sr_flag='d', lr_count=-1, lr_nc=0, cn=0.0):
@@ -97,6 +102,187 @@ class BreakpointGraph:
 
     def compute_cn_lr(self, normal_cov_lr):
         compute_cn_lr(self, normal_cov_lr)
+
+    # -- what the (unchanged) cycle step calls on every graph it receives ------------------------------
+    def infer_max_seq_multiplicity(self, gain=5.0, size_cutoff=10000, multiplicity=2):
+        """Largest multiplicity a sequence edge may take in a cycle / path (bg:609-627): over the edges of at least
+        ``size_cutoff`` bp and CN >= ``gain``, round(max CN / length-weighted mean CN) + 1; ``multiplicity`` without any."""
+        return infer_max_seq_multiplicity(self.sequence_edges, gain, size_cutoff, multiplicity)
+
+    def infer_discordant_edge_multiplicities(self, max_multiplicity=5):
+        """One multiplicity per discordant edge from the long-read supports (bg:630-693; called at cd:146, :623, :1029)."""
+        return discordant_edge_multiplicities([e[9] for e in self.discordant_edges], max_multiplicity)
+
+    # -- container maintenance of the reference class (bg:142-164, :210-253) ---------------------------
+    def del_endnode(self, node_):
+        if node_ in self.endnodes:
+            del self.endnodes[node_]
+        else:
+            warnings.warn("Node corresponding to interval end not exists.")
+
+    def del_discordant_endnodes(self):
+        for nd in [nd for nd, edges in self.endnodes.items() if len(edges) > 0]:
+            del self.endnodes[nd]
+
+    def _drop_and_renumber(self, adjacency_lists, gone, index_map):
+        # the reference's loop (bg:217-228, :248-253): `del lst[i]` inside `for i in range(len(lst))`, kept literally so the
+        # behaviour (including its IndexError when an entry is deleted before the end of a list) is the same
+        for lst in adjacency_lists:
+            for i in range(len(lst)):
+                if lst[i] in gone:
+                    del lst[i]
+                else:
+                    lst[i] = index_map[lst[i]]
+
+    def del_discordant_edges(self, del_list, bpi_map):
+        gone = sorted(del_list, reverse=True)
+        for k in gone:
+            del self.discordant_edges[k]
+        self._drop_and_renumber(self.endnodes.values(), gone, bpi_map)
+        self._drop_and_renumber([adj[2] for adj in self.nodes.values()], gone, bpi_map)
+
+    def del_source_edges(self, del_list, srci_map):
+        gone = sorted(del_list, reverse=True)
+        for k in gone:
+            del self.source_edges[k]
+        self._drop_and_renumber([adj[3] for adj in self.nodes.values()], gone, srci_map)
+
+    # -- walks along the sequence edges used by the graph readers (bg:696-765) -------------------------
+    def _walk(self, chr, pos, cutoff, here, ahead, step):
+        """Distance walked from ``pos`` over consecutive sequence edges until a node with breakpoint edges or ``cutoff``.
+        ``here(p)`` = node whose discordant list stops the walk, ``ahead(p)`` = node whose sequence edge is crossed next."""
+        dist, p = -1, pos
+        while ahead(p) in self.nodes:
+            if p != pos and len(self.nodes[here(p)][2]) > 0:
+                break
+            if dist >= cutoff:
+                break
+            seglen = self.sequence_edges[self.nodes[ahead(p)][0][0]][7]
+            dist = max(dist, 0) + seglen
+            p += step * seglen
+        return dist
+
+    def nextminus(self, chr, pos, min_bp_match_cutoff_=100):
+        return self._walk(chr, pos, min_bp_match_cutoff_, lambda p: (chr, p, '-'), lambda p: (chr, p, '-'), +1)
+
+    def lastminus(self, chr, pos, min_bp_match_cutoff_=100):
+        return self._walk(chr, pos, min_bp_match_cutoff_, lambda p: (chr, p, '-'), lambda p: (chr, p - 1, '+'), -1)
+
+    def nextplus(self, chr, pos, min_bp_match_cutoff_=100):
+        return self._walk(chr, pos, min_bp_match_cutoff_, lambda p: (chr, p, '+'), lambda p: (chr, p + 1, '-'), +1)
+
+    def lastplus(self, chr, pos, min_bp_match_cutoff_=100):
+        return self._walk(chr, pos, min_bp_match_cutoff_, lambda p: (chr, p, '+'), lambda p: (chr, p, '+'), -1)
+
+
+# ----------------------------------------------------------------------------------------------
+# multiplicities for the cycle step (bg:17-80, :609-693)
+# ----------------------------------------------------------------------------------------------
+def infer_max_seq_multiplicity(sequence_edges, gain=5.0, size_cutoff=10000, multiplicity=2):
+    big = [(e[-1], e[7]) for e in sequence_edges if e[7] >= size_cutoff and e[-1] >= gain]
+    if not big:
+        return multiplicity
+    cn, size = [b[0] for b in big], [b[1] for b in big]
+    return int(round(max(cn) / np.average(cn, weights=size))) + 1
+
+
+def _level_above(ratio, level):
+    """Smallest multiplicity m >= level with ratio < m + 0.5 (the reference avoids int(round()) on .5 ties, bg:682-683)."""
+    while ratio >= level + 0.5:
+        level += 1
+    return level
+
+
+def _score_run(rc, lo, hi, max_multiplicity):
+    """One run rc[lo..hi] of the ascending supports: can it be explained as a base group of multiplicity 1 followed by
+    groups of multiplicity 2, 3, ...?  Returns (valid, index of the last base entry, score) — ``test_clustering`` (bg:17-71).
+    Score = Σ log2 jumps between consecutive groups − Σ |m − mean(group / base mean)|; a run needs Σ deviations < 1."""
+    if lo == hi:
+        return True, lo, 0.0
+    p = rc[lo:hi + 1]
+    if p[-1] < p[0] * 2.0:
+        return True, hi, 0.0
+    n_base = next(k for k in range(len(p)) if not p[k] < p[0] * 2.0)
+    if p[-1] / np.average(p[:n_base]) >= max_multiplicity + 0.5:
+        return False, None, None
+    best_score, best_base, best_dev = -10.0, n_base, 1.0
+    for nb in range(n_base, 0, -1):                      # shrink the base group from the right
+        base = np.average(p[:nb])
+        if p[nb] / base < 1.5:
+            continue
+        m = _level_above(p[nb] / base, 2)
+        jumps = math.log2(p[nb]) - math.log2(p[nb - 1])
+        groups, start = {}, nb
+        for i in range(nb, len(p)):
+            if p[i] / base >= m + 0.5:
+                jumps += math.log2(p[i]) - math.log2(p[i - 1])
+                groups[m] = (start, i - 1)
+                start = i
+                m = _level_above(p[i] / base, m)
+        groups[m] = (start, len(p) - 1)
+        if m > max_multiplicity:
+            continue
+        if any(b - a >= nb for a, b in groups.values()):     # no group may outnumber the base group
+            continue
+        dev = sum([abs(mm - np.average(p[groups[mm][0]: groups[mm][1] + 1] / base)) for mm in range(2, m + 1) if mm in groups])
+        if jumps - dev > best_score:
+            best_score, best_dev, best_base = jumps - dev, dev, nb
+    if best_dev < 1.0:
+        return True, best_base + lo - 1, best_score
+    return False, None, None
+
+
+def discordant_edge_multiplicities(supports, max_multiplicity=5):
+    """Multiplicity of every discordant edge from its long-read support (bg:630-693).
+
+    Supports within a factor of two of each other all get 1.  Otherwise the ascending supports are cut into the FEWEST
+    contiguous runs that are each explainable by ``_score_run``; among the cuttings with that many runs the one with the
+    largest Σ run scores + Σ log2 gaps between neighbouring runs wins (first one in lexicographic order of the cut
+    positions on ties), and inside every run the entries after the base group get the multiplicity their ratio to the
+    base mean rounds to (never decreasing along the run)."""
+    from itertools import combinations
+    n = len(supports)
+    if n == 0:
+        return []
+    order = np.argsort(supports)
+    rc = sorted(supports)
+    if math.log2(rc[-1]) - math.log2(rc[0]) < 1.0:
+        return [1] * n
+    best = None
+    for n_runs in range(1, n + 1):
+        best_total = -10.0
+        for cuts in combinations(range(1, n), n_runs - 1):
+            bounds = [0] + list(cuts) + [n]
+            runs = [(bounds[k], bounds[k + 1] - 1) for k in range(n_runs)]
+            total, bases = 0.0, []
+            for k, (lo, hi) in enumerate(runs):
+                ok, base_end, score = _score_run(rc, lo, hi, max_multiplicity)
+                if not ok:
+                    break
+                total += score
+                bases.append(base_end)
+                if k > 0:
+                    total += math.log2(rc[lo]) - math.log2(rc[runs[k - 1][1]])
+            else:
+                if best is None:
+                    best = ([], [])                       # a valid cutting exists at this run count
+                if total > best_total:
+                    best_total, best = total, (runs, bases)
+        if best is not None:
+            break
+    runs, bases = best
+    in_sorted = []
+    for (lo, hi), base_end in zip(runs, bases):
+        in_sorted += [1] * (base_end - lo + 1)
+        if base_end + 1 > hi:
+            continue
+        base = np.average(rc[lo: base_end + 1])
+        m = _level_above(rc[base_end + 1] / base, 2)
+        for i in range(base_end + 1, hi + 1):
+            m = _level_above(rc[i] / base, m)
+            in_sorted.append(m)
+    rank = {int(src): k for k, src in enumerate(order)}        # position of edge i in the ascending order
+    return [in_sorted[rank[i]] for i in range(n)]
 
 
 # ----------------------------------------------------------------------------------------------
@@ -210,7 +396,19 @@ def solve_cn_lr(w_inv, w_lin, w_log, A, max_iter=200):
         r = r_new
         if small:
             break
+    # a stalled solve must not pass silently: relative KKT residual of the returned point (stationarity scaled by the gradient
+    # terms, balance by the flows); the exact optimum sits at ~1e-13, cvxopt's own stopping rule at ~1e-7
+    res = kkt_residual(x, nu)
+    scale = max(1.0, float(np.max(np.abs(w_lin) + np.abs(w_log) / x + np.abs(w_inv) / (x * x))))
+    solve_cn_lr.last_residual = float(np.max(np.abs(res[:n])) / scale) if n else 0.0
+    if p:
+        solve_cn_lr.last_residual = max(solve_cn_lr.last_residual, float(np.max(np.abs(res[n:])) / max(1.0, float(np.max(x)))))
+    if not solve_cn_lr.last_residual < 1e-8:
+        raise ArithmeticError("CN assignment did not converge (relative KKT residual %.3g)" % solve_cn_lr.last_residual)
     return x
+
+
+solve_cn_lr.last_residual = 0.0
 
 
 def compute_cn_lr(g, normal_cov_lr):

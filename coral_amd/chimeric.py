@@ -61,9 +61,11 @@ def build_chimeric_table(dr) -> ChimericTable:
     from . import _lib
     T = ChimericTable()
     cnt, s0, s1 = C.c_int64(0), C.c_double(0.0), C.c_double(0.0)
-    _lib.check(_lib.lib().coral_nm_stats(dr.n_total, dr.h_tid.ctypes.data, dr.h_sa_off.ctypes.data, dr.h_mapq.ctypes.data,
-                                         dr.h_nm.ctypes.data, dr.h_qlen.ctypes.data, C.byref(cnt), C.byref(s0), C.byref(s1)),
-               "coral_nm_stats")
+    rc = _lib.lib().coral_nm_stats(dr.n_total, dr.h_tid.ctypes.data, dr.h_sa_off.ctypes.data, dr.h_mapq.ctypes.data,
+                                   dr.h_nm.ctypes.data, dr.h_qlen.ctypes.data, C.byref(cnt), C.byref(s0), C.byref(s1))
+    if rc == -5:                                  # CORAL_ERR_ZERODIV: a counted record without SEQ (ibg:154)
+        raise ZeroDivisionError("division by zero")
+    _lib.check(rc, "coral_nm_stats")
     T.n_mapq60_plain, T.nm_sum, T.nm_sum_sq = int(cnt.value), float(s0.value), float(s1.value)
     cols, off, name_id, failed, rl = kernels.sa_table(dr)
     T.read_length = rl

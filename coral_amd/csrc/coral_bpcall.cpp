@@ -161,7 +161,9 @@ extern "C" int coral_call_breakpoints(int64_t n, const int64_t *const *field_ptr
     std::unordered_map<int64_t, int32_t> group_of;
     std::vector<std::vector<int64_t>> groups;
     for (int64_t i = 0; i < n; ++i) {
-        const int64_t key = ((c.at(C1, i) * 64 + c.at(C2, i)) * 2 + c.at(O1, i)) * 2 + c.at(O2, i);
+        // (chr1, chr2, o1, o2) as one key: 31 bits per contig id (BAM refIDs are int32), no assumption about the header's size
+        const int64_t key = (((c.at(C1, i) & 0x7fffffffLL) << 33) | ((c.at(C2, i) & 0x7fffffffLL) << 2) | ((c.at(O1, i) & 1) << 1) |
+                             (c.at(O2, i) & 1));
         auto it = group_of.find(key);
         if (it == group_of.end()) {
             group_of.emplace(key, (int32_t)groups.size());

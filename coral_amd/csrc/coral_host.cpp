@@ -332,6 +332,7 @@ extern "C" int coral_nm_stats(int64_t n, const int32_t *tid, const int64_t *sa_o
     double s0 = 0.0, s1 = 0.0;
     for (int64_t i = 0; i < n; ++i) {
         if (tid[i] < 0 || sa_off[i + 1] > sa_off[i] || mapq[i] != 60) continue;
+        if (qlen[i] == 0) return CORAL_ERR_ZERODIV;      // record without SEQ: NM / query_length raises in the reference (ibg:154)
         const double e = (double)nm[i] / (double)qlen[i];
         const double e2 = e * e;
         s0 += e;

@@ -278,7 +278,7 @@ extern "C" int coral_sa_table(int32_t n_rec, const int32_t *rec_tid, const int32
     if (e != hipSuccess) return sa_err(CORAL_ERR_HIP, hipGetErrorString(e));
     if (h[0] == 2) return sa_err(CORAL_ERR_ARG, "sa_table: a read has more than 64 distinct SA entries");
     if (h[0] == 3) return sa_err(CORAL_ERR_FORMAT, "sa_table: SA CIGAR shape outside SM/MS/SMS/SMD/MDS/SMDS/SMI/MIS/SMIS");
-    if (h[0] == 4) return sa_err(CORAL_ERR_FORMAT - 1, "sa_table: zero-length query interval (ZeroDivisionError in the reference)");
+    if (h[0] == 4) return sa_err(CORAL_ERR_ZERODIV, "sa_table: zero-length query interval (ZeroDivisionError in the reference)");
     const int n_reads = h[1];
     if (n_reads > 0) {
         hipLaunchKernelGGL(k_scatter, dim3((n_reads + B - 1) / B), dim3(B), 0, s, n_reads, g_sorted, off, gstart, keys_s, n_kept,

@@ -88,9 +88,15 @@ class DeviceRecords:
         self.total_ops = int(self.h_n_cigar[lo:hi].astype(np.int64).sum())
         self.n_sa_local = int(self.h_sa_off[hi] - self.h_sa_off[lo]) if self.n_total else 0
         self.n_sa = int(self.h_sa.shape[0])
+        # per-contig record ranges of the coordinate-sorted file; unplaced reads (refID -1) sit at the END of a sorted BAM, so
+        # the binary search runs over the mapped prefix only
+        n_mapped = int(np.count_nonzero(self.h_tid >= 0))
+        mapped = self.h_tid[:n_mapped]
+        if n_mapped and (bool((mapped < 0).any()) or bool((np.diff(mapped) < 0).any())):
+            raise ValueError("records are not sorted by contig (mapped records first, in header order): sort the BAM by coordinate")
         t = np.arange(len(self.header_chroms))
-        self.tid_lo = np.searchsorted(self.h_tid, t, side="left")
-        self.tid_hi = np.searchsorted(self.h_tid, t, side="right")
+        self.tid_lo = np.searchsorted(mapped, t, side="left")
+        self.tid_hi = np.searchsorted(mapped, t, side="right")
 
     @property
     def names(self) -> List[str]:

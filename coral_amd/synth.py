@@ -264,6 +264,14 @@ def write_cn_bed(cfg: SynthConfig, path: str) -> None:
             fp.write(f"{c}\t{s}\t{e}\t{cn}\n")
 
 
+def write_cn_cns(cfg: SynthConfig, path: str) -> None:
+    """The same segments in cnvkit's ``.cns`` flavour (ibg:94-95): header line, log2 ratio in column 5, CN = 2 * 2**log2."""
+    with open(path, "w") as fp:
+        fp.write("chromosome\tstart\tend\tgene\tlog2\tdepth\tprobes\tweight\n")
+        for c, s, e, cn in cn_segments(cfg):
+            fp.write(f"{c}\t{s}\t{e}\t-\t{np.log2(cn / 2.0):.6f}\t{cn * 10:.3f}\t{(e - s) // 1000}\t1.0\n")
+
+
 def write_seed_bed(cfg: SynthConfig, path: str) -> None:
     with open(path, "w") as fp:
         for tid, s, e in cfg.seeds:
@@ -895,5 +903,14 @@ def dataset(name: str, device="cpu") -> Tuple[SynthConfig, Records]:
         cfg.name = "hsr_edge"
         rec = merge_sorted(generate(cfg, "cpu"), records_from_alignments(_hsr_edge_alignments(cfg)))
         return cfg, (rec if str(device) == "cpu" else rec.to(device))
+    if name in ("cfg3_12k", "cfg3_2amp"):
+        # the headline configuration's layout (3 chromosomes, 3 circles x 8 segments, 10 seeds) at a read count the unmodified
+        # reference finishes in seconds: 12 000 reads x 20 kb reproduce config 3's graph shape (1 amplicon, 28 discordant
+        # edges); 6 000 reads x 8 kb leave the amplicon in two connected components (two ccids -> two graph files)
+        cfg = scaled_config("cfg3", 12000 if name == "cfg3_12k" else 6000)
+        if name == "cfg3_2amp":
+            cfg.mean_len = 8000
+        cfg.name = name
+        return cfg, generate(cfg, device)
     cfg = named_config(name)
     return cfg, generate(cfg, device)

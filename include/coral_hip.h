@@ -39,6 +39,7 @@ extern "C" {
 #define CORAL_ERR_HIP (-2)        /* a HIP runtime call failed */
 #define CORAL_ERR_CAPACITY (-3)   /* an output list overflowed; *count holds the needed size */
 #define CORAL_ERR_FORMAT (-4)     /* malformed BAM / BGZF input */
+#define CORAL_ERR_ZERODIV (-5)    /* a division the reference performs has a zero divisor (ZeroDivisionError there) */
 
 typedef struct coral_records {
     int64_t n_rec;
@@ -121,7 +122,7 @@ int coral_point_cover(const coral_records_t *rec, int32_t n_pts, const int32_t *
  *           out_read_length int32[n_names] (-1 = no primary seen);  counts (HOST) = {n_reads, n_rows}
  * `workspace` is device scratch; when it is too small the call returns CORAL_ERR_CAPACITY with counts[0] = MiB needed.
  * Errors mirror the reference: CORAL_ERR_FORMAT = SA CIGAR outside the nine shapes (KeyError, cp:255),
- * CORAL_ERR_FORMAT - 1 = zero-length query interval (ZeroDivisionError, cp:268).  Synchronises `stream`.
+ * CORAL_ERR_ZERODIV = zero-length query interval (ZeroDivisionError, cp:268).  Synchronises `stream`.
  * ------------------------------------------------------------------------------------------------ */
 int coral_sa_table(int32_t n_rec, const int32_t *rec_tid, const int32_t *rec_flagmq, const int32_t *rec_qlen,
                    const int32_t *rec_name, int32_t n_names, int32_t n_sa, const int32_t *sa, const int32_t *sa_nm,
@@ -234,7 +235,8 @@ int coral_call_breakpoints(int64_t n, const int64_t *const *field_ptr, const int
 
 /* NM statistics of the mapped, non-chimeric (no SA tag) MAPQ-60 records, ibg:153-157: their count and the sums of
  * e = NM / query_length and of e * e, added in record order with one rounding per addition (the reference's sequential
- * `+=`).  Host arrays: tid / mapq / nm / qlen int32[n], sa_off int64[n + 1] (SA rows per record). */
+ * `+=`).  Host arrays: tid / mapq / nm / qlen int32[n], sa_off int64[n + 1] (SA rows per record).
+ * CORAL_ERR_ZERODIV when a counted record has query_length 0 (no SEQ): the reference raises ZeroDivisionError at ibg:154. */
 int coral_nm_stats(int64_t n, const int32_t *tid, const int64_t *sa_off, const int32_t *mapq, const int32_t *nm,
                    const int32_t *qlen, int64_t *count, double *sum_e, double *sum_e2);
 

@@ -434,6 +434,119 @@ class OracleBreakpointGraph:
         self.max_cn += 1.0
 
 
+# ---- multiplicities handed to the cycle step (bg:17-80, bg:609-693) ----
+def _cluster_test(rc, part, max_multiplicity=5):
+    """bg:17-71: (valid, index of the last multiplicity-1 entry, score) of the run rc[part[0]..part[1]] (ascending)."""
+    a, b = part
+    if a == b:                                               # bg:18-19
+        return True, a, 0.0
+    p = rc[a:b + 1]
+    if p[-1] < p[0] * 2.0:                                   # bg:21-22
+        return True, b, 0.0
+    k0 = 0
+    while k0 < len(p) and p[k0] < p[0] * 2.0:                # bg:23-25
+        k0 += 1
+    if p[-1] / np.average(p[:k0]) >= max_multiplicity + 0.5:  # bg:26-28
+        return False, None, None
+    score, best, dev_best = -10.0, k0, 1.0
+    k = k0
+    while k >= 1:                                            # bg:32 (base group shrinks from the right)
+        mean = np.average(p[:k])
+        m = 2
+        if not p[k] / mean < m - 0.5:                        # bg:40-41
+            while p[k] / mean >= m + 0.5:                    # bg:42-43
+                m += 1
+            gap = math.log2(p[k]) - math.log2(p[k - 1])      # bg:44
+            spans = {}
+            left = k
+            for i in range(k, len(p)):                       # bg:47-53
+                if p[i] / mean >= m + 0.5:
+                    gap += math.log2(p[i]) - math.log2(p[i - 1])
+                    spans[m] = [left, i - 1]
+                    left = i
+                    while p[i] / mean >= m + 0.5:
+                        m += 1
+            spans[m] = [left, len(p) - 1]                    # bg:54
+            fits = m <= max_multiplicity                     # bg:55-56
+            for mm in range(2, m + 1):                       # bg:57-63
+                if mm in spans and spans[mm][1] - spans[mm][0] >= k:
+                    fits = False
+            if fits:
+                dev = sum([abs(mm - np.average(p[spans[mm][0]: spans[mm][1] + 1] / mean))
+                           for mm in range(2, m + 1) if mm in spans])       # bg:64
+                if gap - dev > score:                        # bg:65-68
+                    score, dev_best, best = gap - dev, dev, k
+        k -= 1
+    if dev_best < 1.0:                                       # bg:69-72
+        return True, best + a - 1, score
+    return False, None, None
+
+
+def _contiguous_partitions(k, start, end):
+    """bg:74-80: every split of start..end into k + 1 non-empty contiguous parts, first part shortest first."""
+    if k == 0:
+        yield [[start, end]]
+        return
+    for first_len in range(1, end - start - k + 2):
+        for rest in _contiguous_partitions(k - 1, start + first_len, end):
+            yield [[start, start + first_len - 1]] + rest
+
+
+def infer_discordant_edge_multiplicities(discordant_edges, max_multiplicity=5):
+    """bg:630-693 on the long-read supports ``e[9]`` of the discordant edges."""
+    rc = [e[9] for e in discordant_edges]
+    if not rc:
+        return []
+    idx = np.argsort(rc)                                      # bg:640
+    rc = sorted(rc)
+    if math.log2(rc[-1]) - math.log2(rc[0]) < 1.0:            # bg:642-643
+        return [1 for _ in idx]
+    n_parts, chosen, chosen_bases, found = 1, [], [], False
+    while not found:                                          # bg:651-677: fewest parts with a valid split
+        top = -10.0
+        for parts in _contiguous_partitions(n_parts - 1, 0, len(rc) - 1):
+            total, bases, ok = 0.0, [], True
+            for pi, part in enumerate(parts):
+                valid, base_end, sc = _cluster_test(rc, part, max_multiplicity)
+                if not valid:
+                    ok = False
+                    break
+                total += sc
+                bases.append([part[0], base_end])
+                if pi > 0:                                    # bg:667-668
+                    total += math.log2(rc[part[0]]) - math.log2(rc[parts[pi - 1][1]])
+            if ok:
+                found = True
+                if total > top:
+                    top, chosen, chosen_bases = total, parts, bases
+        n_parts += 1
+    out_sorted = []
+    for part, (b0, b1) in zip(chosen, chosen_bases):          # bg:678-692
+        out_sorted += [1] * (b1 - b0 + 1)
+        nxt = b1 + 1
+        if nxt > part[1]:
+            continue
+        mean = np.average(rc[b0: b1 + 1])
+        m = 2
+        while rc[nxt] / mean >= m + 0.5:
+            m += 1
+        for i in range(nxt, part[1] + 1):
+            while rc[i] / mean >= m + 0.5:
+                m += 1
+            out_sorted.append(m)
+    where = list(idx)
+    return [out_sorted[where.index(i)] for i in range(len(rc))]            # bg:693
+
+
+def infer_max_seq_multiplicity(sequence_edges, gain=5.0, size_cutoff=10000, multiplicity=2):
+    """bg:609-627."""
+    cns = [e[-1] for e in sequence_edges if e[7] >= size_cutoff and e[-1] >= gain]
+    lens = [e[7] for e in sequence_edges if e[7] >= size_cutoff and e[-1] >= gain]
+    if cns:
+        return int(round(max(cns) / np.average(cns, weights=lens))) + 1
+    return multiplicity
+
+
 def solve_cn(inv, lin, lg, A, max_iter=200):
     """minimise Σ inv/x + lin·x − lg·log x  s.t.  A x = 0, x > 0  (objective bg:546-556), from x = 1.
 

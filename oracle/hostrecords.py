@@ -62,8 +62,10 @@ class HostRecords:
         self.nonacgt_pos = g(rec.nonacgt_pos).astype(np.int64)
         self.tid_of = {c: k for k, c in enumerate(self.chroms)}
         t = np.arange(len(self.chroms))
-        self._lo = np.searchsorted(self.tid, t, side="left")
-        self._hi = np.searchsorted(self.tid, t, side="right")
+        mapped = self.tid[:int(np.count_nonzero(self.tid >= 0))]     # unplaced reads (tid -1) end a coordinate-sorted file
+        assert not (mapped < 0).any() and not (np.diff(mapped) < 0).any(), "records must be sorted by contig"
+        self._lo = np.searchsorted(mapped, t, side="left")
+        self._hi = np.searchsorted(mapped, t, side="right")
 
     # -- pysam-like primitives ------------------------------------------------------------
     def ops(self, i):

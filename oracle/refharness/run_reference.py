@@ -79,6 +79,8 @@ def main():
     ap.add_argument("out_json")
     ap.add_argument("--output_bp", action="store_true")
     ap.add_argument("--min_bp_support", type=float, default=1.0)
+    ap.add_argument("--cn_format", default="bed", choices=["bed", "cns"],
+                    help="flavour of the CN segment file (ibg:94-98): .bed (CN in column 4) or .cns (log2 ratio in column 5)")
     a = ap.parse_args()
     assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0"
 
@@ -89,9 +91,9 @@ def main():
     tmp = tempfile.mkdtemp(prefix="coral_ref_")
     bam = os.path.join(tmp, "synthetic.bam")
     fake_pysam.register(bam, fake_pysam.records_to_host(rec))
-    cn = os.path.join(tmp, "cn.bed")
+    cn = os.path.join(tmp, "cn." + a.cn_format)
     seedf = os.path.join(tmp, "seeds.bed")
-    synth.write_cn_bed(cfg, cn)
+    (synth.write_cn_bed if a.cn_format == "bed" else synth.write_cn_cns)(cfg, cn)
     synth.write_seed_bed(cfg, seedf)
     prefix = os.path.join(tmp, "out")
 
@@ -103,7 +105,7 @@ def main():
     logging.basicConfig(filename=os.path.join(tmp, "ref.log"), filemode="w", level=logging.DEBUG)
 
     snap = {"config": a.config, "records_sha256": records_digest(rec), "n_records": rec.n,
-            "python_hash_seed": 0, "min_bp_support": a.min_bp_support}
+            "python_hash_seed": 0, "min_bp_support": a.min_bp_support, "cn_format": a.cn_format}
     # same call sequence as reconstruct_graph (/root/reference/src/infer_breakpoint_graph.py:1349-1394)
     b = ibg.bam_to_breakpoint_nanopore(bam, seedf)
     b.min_bp_cov_factor = a.min_bp_support
@@ -149,6 +151,9 @@ def main():
             b.lr_graph[gi].compute_cn_lr(b.normal_cov)
         snap["A11"] = dict(graphs=[graph_snapshot(g) for g in b.lr_graph],
                            cn_solver="oracle/refharness/fake_cvxopt.py (NOT cvxopt; CN parity vs cvxopt unpinned)")
+        # what the cycle step asks of every graph it is handed (cd:146, :623, :1029; companion bg:609-627)
+        snap["A11x"] = dict(discordant_edge_multiplicities=[_js(g.infer_discordant_edge_multiplicities()) for g in b.lr_graph],
+                            max_seq_multiplicity=[_js(g.infer_max_seq_multiplicity()) for g in b.lr_graph])
         for gi in range(len(b.lr_graph)):
             fn = prefix + "_amplicon" + str(gi + 1) + "_graph.txt"
             bg.output_breakpoint_graph_lr(b.lr_graph[gi], fn)

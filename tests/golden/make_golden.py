@@ -31,6 +31,9 @@ E2E_CASES = [
     ("tiny_edge", []),
     ("small", []),
     ("ultra", []),
+    ("tiny", ["--cn_format", "cns"]),           # the .cns flavour of the CN segment file (ibg:94-95)
+    ("cfg3_12k", []),                            # BASELINE config 3's layout at 12 000 reads: same graph shape as the full run
+    ("cfg3_2amp", []),                           # config 3's layout, two amplicons (two ccids -> two graph files)
 ]
 
 
@@ -195,10 +198,88 @@ def unit_vectors():
     return out
 
 
+def graph_method_vectors():
+    """graph_methods.json: known answers of the BreakpointGraph methods the cycle step relies on
+    (/root/reference/src/breakpoint_graph.py:609-765), from the reference class itself (imported behind the cvxopt stub:
+    these methods do not touch the solver)."""
+    sys.path.insert(0, ROOT)
+    from oracle.refharness import run_reference as rr
+    rr._install_stubs()
+    import breakpoint_graph as bg
+    rnd = random.Random(20241025)
+    out = {}
+    v = []
+    for k in range(400):
+        n = rnd.randint(1, 9)
+        style = k % 4
+        if style == 0:
+            rc = [rnd.randint(1, 60) for _ in range(n)]
+        elif style == 1:
+            base = rnd.randint(3, 40)
+            rc = [max(1, int(base * rnd.choice([1, 1, 1, 2, 2, 3, 4, 5]) * rnd.uniform(0.8, 1.2))) for _ in range(n)]
+        elif style == 2:
+            rc = [rnd.randint(1, 400) for _ in range(n)]
+        else:
+            base = rnd.randint(20, 200)
+            rc = [max(1, int(base * rnd.choice([1, 1, 2, 3, 6, 7]) * rnd.uniform(0.95, 1.05))) for _ in range(n)]
+        g = bg.BreakpointGraph()
+        g.discordant_edges = [["chr8", 1, "+", "chr8", 2, "-", -1, "d", 0.0, c, set(), 0.0] for c in rc]
+        try:
+            res = g.infer_discordant_edge_multiplicities()
+        except Exception as exc:                     # noqa: BLE001 — the exception type is the known answer
+            res = {"raises": type(exc).__name__}
+        v.append(dict(lr_counts=rc, out=res))
+    out["discordant_edge_multiplicities"] = v
+    v = []
+    for k in range(80):
+        n = rnd.randint(0, 8)
+        edges = []
+        for _ in range(n):
+            size = rnd.choice([500, 9999, 10000, 25000, 180000, 1200000])
+            cn = round(rnd.choice([1.9, 2.0, 4.99, 5.0, 12.5, 40.0, 83.3]) * rnd.uniform(0.9, 1.1), 4)
+            edges.append(["chr8", 1000, 1000 + size - 1, -1, "d", 10, 1000, size, cn])
+        g = bg.BreakpointGraph()
+        g.sequence_edges = edges
+        kw = [{}, {"gain": 4.0}, {"size_cutoff": 500, "multiplicity": 3}][k % 3]
+        v.append(dict(sequence_edges=edges, kwargs=kw, out=g.infer_max_seq_multiplicity(**kw)))
+    out["max_seq_multiplicity"] = v
+    # walks along consecutive sequence edges (bg:696-765) on chains with breakpoint edges at random nodes
+    v = []
+    for k in range(60):
+        g = bg.BreakpointGraph()
+        pos = 10000
+        cuts = [pos]
+        for _ in range(rnd.randint(1, 6)):
+            pos += rnd.choice([1, 30, 60, 99, 100, 101, 400])
+            cuts.append(pos)
+        segs = [(cuts[i], cuts[i + 1] - 1) for i in range(len(cuts) - 1)]
+        for (l, r) in segs:
+            g.add_node(("chr8", l, "-"))
+            g.add_node(("chr8", r, "+"))
+            g.add_sequence_edge("chr8", l, r)
+        for i in range(len(segs) - 1):
+            g.add_concordant_edge("chr8", segs[i][1], "+", "chr8", segs[i + 1][0], "-")
+        marks = []
+        for nd in list(g.nodes):
+            if rnd.random() < 0.25:
+                g.add_discordant_edge(nd[0], nd[1], nd[2], nd[0], nd[1], nd[2])
+                marks.append(list(nd))
+        queries = []
+        for (l, r) in segs:
+            for cutoff in (100, 0):
+                queries.append(dict(pos=[l, r], cutoff=cutoff,
+                                    nextminus=g.nextminus("chr8", l, cutoff), lastminus=g.lastminus("chr8", l, cutoff),
+                                    nextplus=g.nextplus("chr8", r, cutoff), lastplus=g.lastplus("chr8", r, cutoff)))
+        v.append(dict(segments=[list(x) for x in segs], discordant_nodes=marks, queries=queries))
+    out["walks"] = v
+    return out
+
+
 def main():
     assert os.path.isdir(REF_SRC), "the reference is only available in the build container"
     with open(os.path.join(HERE, "unit_vectors.json"), "w") as fp:
         json.dump(unit_vectors(), fp, separators=(",", ":"))
+    graph_methods_only()
     env = dict(os.environ, PYTHONHASHSEED="0")
     for cfg, extra in E2E_CASES:
         tag = cfg + "".join("_" + x.strip("-").replace(".", "p") for x in extra)
@@ -208,6 +289,11 @@ def main():
         subprocess.run(cmd, cwd=ROOT, env=env, check=True, stdout=subprocess.DEVNULL)
     hsr_only()
     print("done")
+
+
+def graph_methods_only():
+    with open(os.path.join(HERE, "graph_methods.json"), "w") as fp:
+        json.dump(graph_method_vectors(), fp, separators=(",", ":"))
 
 
 def hsr_only():
@@ -270,6 +356,8 @@ if __name__ == "__main__":
         plotcov_only()
     elif sys.argv[1:] == ["cycles"]:
         cycles_only()
+    elif sys.argv[1:] == ["graph_methods"]:
+        graph_methods_only()
     else:
         main()
         plotcov_only()

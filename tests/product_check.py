@@ -52,8 +52,9 @@ def check_product_against_golden(case, golden_dir, tmp_path, device):
     from coral_amd.breakpoint_graph import breakpoint_info_text, compute_cn_lr, graph_text
     from coral_amd.records import DeviceRecords
     gold, cfg, rec = load_case(golden_dir, case)
-    cn = str(tmp_path / "cn.bed"); seeds = str(tmp_path / "seeds.bed")
-    synth.write_cn_bed(cfg, cn); synth.write_seed_bed(cfg, seeds)
+    fmt = gold.get("cn_format", "bed")
+    cn = str(tmp_path / ("cn." + fmt)); seeds = str(tmp_path / "seeds.bed")
+    (synth.write_cn_bed if fmt == "bed" else synth.write_cn_cns)(cfg, cn); synth.write_seed_bed(cfg, seeds)
     dr = DeviceRecords(rec, device)
     b = ibg.bam_to_breakpoint_nanopore(None, seeds, records=dr)
     b.min_bp_cov_factor = gold["min_bp_support"]
@@ -116,6 +117,9 @@ def check_product_against_golden(case, golden_dir, tmp_path, device):
             sg, cng = strip_cn(gg)
             assert s == sg
             cn_close(cns, cng)
+        # what the cycle step asks of each graph it receives (cd:146, :623, :1029; bg:609-693)
+        assert [g.infer_discordant_edge_multiplicities() for g in b.lr_graph] == gold["A11x"]["discordant_edge_multiplicities"]
+        assert [g.infer_max_seq_multiplicity() for g in b.lr_graph] == gold["A11x"]["max_seq_multiplicity"]
         files = {"out_amplicon%d_graph.txt" % (gi + 1): graph_text(g) for gi, g in enumerate(b.lr_graph)}
         assert sorted(files) == sorted(gold["files"])
         for k in files:

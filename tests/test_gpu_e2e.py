@@ -11,13 +11,24 @@ from coral_amd import synth
 from tests.product_check import HASHSEED0, check_product_against_golden
 
 pytestmark = pytest.mark.gpu
-CASES = ["tiny", "tiny_output_bp", "tiny_min_bp_support_30p0", "tiny_edge", "small", "ultra"]
+CASES = ["tiny", "tiny_output_bp", "tiny_min_bp_support_30p0", "tiny_edge", "small", "ultra", "tiny_cn_format_cns", "cfg3_12k", "cfg3_2amp"]
 
 
 @pytest.mark.parametrize("case", CASES)
 def test_gpu_matches_reference_golden(case, golden_dir, tmp_path):
     b = check_product_against_golden(case, golden_dir, tmp_path, "cuda:0")
     assert b.rec.device.type == "cuda"
+
+
+def test_cycle_step_surface_on_gpu_build(tmp_path):
+    """Every attribute / method cycle_decomposition.py and path_constraints.py touch, on the object a GPU build returns."""
+    from coral_amd import infer_breakpoint_graph as ibg
+    from coral_amd.records import DeviceRecords
+    from tests.test_graph_methods import check_surface
+    cfg, rec = synth.dataset("small", "cpu")
+    cn, seeds = str(tmp_path / "cn.bed"), str(tmp_path / "seeds.bed")
+    synth.write_cn_bed(cfg, cn); synth.write_seed_bed(cfg, seeds)
+    check_surface(ibg.build_graph_from_records(DeviceRecords(rec, "cuda:0"), seeds, cn, str(tmp_path / "out")))
 
 
 @pytest.mark.skipif(HASHSEED0, reason="already running with PYTHONHASHSEED=0")

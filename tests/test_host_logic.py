@@ -9,7 +9,7 @@ import pytest
 
 from tests.product_check import HASHSEED0, check_product_against_golden, install_cpu_kernel_fakes
 
-CASES = ["tiny", "tiny_output_bp", "tiny_min_bp_support_30p0", "tiny_edge", "small", "ultra"]
+CASES = ["tiny", "tiny_output_bp", "tiny_min_bp_support_30p0", "tiny_edge", "small", "ultra", "tiny_cn_format_cns", "cfg3_12k", "cfg3_2amp"]
 
 
 @pytest.mark.parametrize("case", CASES)

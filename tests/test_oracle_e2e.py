@@ -14,7 +14,7 @@ from oracle import coral_oracle as O
 from oracle.hostrecords import HostRecords
 from tests.canon import canon, graph_snapshot, records_digest, strip_cn
 
-CASES = ["tiny", "tiny_output_bp", "tiny_min_bp_support_30p0", "tiny_edge", "small", "ultra"]
+CASES = ["tiny", "tiny_output_bp", "tiny_min_bp_support_30p0", "tiny_edge", "small", "ultra", "tiny_cn_format_cns", "cfg3_12k", "cfg3_2amp"]
 HASHSEED0 = os.environ.get("PYTHONHASHSEED") == "0"
 _cache = {}
 
@@ -44,8 +44,9 @@ def norm_bps(lst):
 @pytest.mark.parametrize("case", CASES)
 def test_oracle_matches_reference(case, golden_dir, tmp_path):
     gold, cfg, rec, host = load_case(golden_dir, case)
-    cn = str(tmp_path / "cn.bed"); seeds = str(tmp_path / "seeds.bed")
-    synth.write_cn_bed(cfg, cn); synth.write_seed_bed(cfg, seeds)
+    fmt = gold.get("cn_format", "bed")
+    cn = str(tmp_path / ("cn." + fmt)); seeds = str(tmp_path / "seeds.bed")
+    (synth.write_cn_bed if fmt == "bed" else synth.write_cn_cns)(cfg, cn); synth.write_seed_bed(cfg, seeds)
     b = O.OracleGraphBuild(host, seeds)
     b.min_bp_cov_factor = gold["min_bp_support"]
     b.read_cns(cn)
@@ -103,6 +104,10 @@ def test_oracle_matches_reference(case, golden_dir, tmp_path):
             sg, cng = strip_cn(gg)
             assert s == sg
             cn_close(cns, cng)          # tolerance 1e-6 relative (north_star); solver != cvxopt: unpinned there
+        # what the cycle step asks of each graph (cd:146; bg:609-693)
+        assert [O.infer_discordant_edge_multiplicities(g.discordant_edges) for g in b.lr_graph] == \
+            gold["A11x"]["discordant_edge_multiplicities"]
+        assert [O.infer_max_seq_multiplicity(g.sequence_edges) for g in b.lr_graph] == gold["A11x"]["max_seq_multiplicity"]
         files = {"out_amplicon%d_graph.txt" % (gi + 1): O.graph_text(g) for gi, g in enumerate(b.lr_graph)}
         assert sorted(files) == sorted(gold["files"])
         for k in files:
