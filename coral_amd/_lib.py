@@ -18,11 +18,6 @@ class coral_records_t(C.Structure):
                 ("flagmq", C.c_void_p), ("n_cigar", C.c_void_p), ("cigar_off", C.c_void_p), ("cigar", C.c_void_p)]
 
 
-class coral_chimeric_t(C.Structure):
-    _fields_ = [("n_reads", C.c_int32), ("off", C.c_void_p), ("qs", C.c_void_p), ("qe", C.c_void_p), ("tid", C.c_void_p),
-                ("ra", C.c_void_p), ("rb", C.c_void_p), ("strand", C.c_void_p), ("mapq", C.c_void_p)]
-
-
 _lib = None
 
 def lib():
@@ -53,9 +48,24 @@ def lib():
     L.coral_time_stream_read.restype = C.c_int
     L.coral_first_seen_rows.argtypes = [C.c_int64, C.c_int32, P, P]
     L.coral_first_seen_rows.restype = C.c_int
-    L.coral_bp_candidates.argtypes = [C.POINTER(coral_chimeric_t), C.c_int32, P, C.c_int32, C.c_int32, P, P, P, P, C.c_int32,
-                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, C.c_int32, C.POINTER(C.c_int32), P]
-    L.coral_bp_candidates.restype = C.c_int
+    L.coral_bp_pair_table.argtypes = [C.c_int32, C.c_int32, P, P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P]
+    L.coral_bp_pair_table.restype = C.c_int
+    L.coral_search_create.argtypes = [C.c_int64, C.c_int64] + [P] * 9 + [C.c_int64, P, P, P, C.c_int32, P, P, P]
+    L.coral_search_create.restype = C.c_void_p
+    L.coral_search_free.argtypes = [C.c_void_p]
+    L.coral_search_free.restype = C.c_int
+    L.coral_search_error.argtypes = [C.c_void_p]
+    L.coral_search_error.restype = C.c_char_p
+    L.coral_search_result.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.c_int64),
+                                      C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.POINTER(C.c_int64)),
+                                      C.POINTER(C.POINTER(C.c_int32))]
+    L.coral_search_result.restype = C.c_int
+    L.coral_search_step.argtypes = [C.c_void_p] + [C.c_int64] * 5 + [C.c_double, C.c_int64]
+    L.coral_search_step.restype = C.c_int
+    L.coral_search_within.argtypes = [C.c_void_p, C.c_int32, P, P, P]
+    L.coral_search_within.restype = C.c_int
+    L.coral_search_between.argtypes = [C.c_void_p, C.c_int64, P] + [C.c_int64] * 6
+    L.coral_search_between.restype = C.c_int
     L.coral_sa_table.argtypes = [C.c_int32, P, P, P, P, C.c_int32, C.c_int32, P, P, P, P, C.c_int64, P, P, P, P, P,
                                  C.POINTER(C.c_int32), P]
     L.coral_sa_table.restype = C.c_int

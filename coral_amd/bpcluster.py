@@ -22,7 +22,7 @@ def cluster_bp_list(c: Candidates, min_cluster_size, bp_distance_cutoff: int) ->
     n = len(c)
     if n == 0:
         return []
-    key = ((c.c1 * 64 + c.c2) * 2 + c.o1) * 2 + c.o2
+    key = (c.c1 << 33) | (c.c2 << 2) | (c.o1 << 1) | c.o2          # any BAM refID (int32) — no limit on the header's size
     _, first, inv = np.unique(key, return_index=True, return_inverse=True)
     group_rank = np.empty(len(first), dtype=np.int64)
     group_rank[np.argsort(first, kind="stable")] = np.arange(len(first))

@@ -34,19 +34,12 @@ class ChimericTable:
             setattr(self, k, np.zeros(0, np.int64))
         self.nm = np.zeros(0, np.float64)
         self.read_length = np.zeros(0, np.int64)      # per name id, -1 = no primary seen
+        self.pairs = np.zeros((0, 8), np.int32)       # coral_bp_pair_table: two slots per row (see csrc/coral_kernels.hip, K4)
         self.n_mapq60_plain = 0
 
     @property
     def n_reads(self):
         return len(self.name_id)
-
-    def device_arrays(self, device):
-        """int32 device copies of (off, qs, qe, tid, ra, rb, strand, mapq), uploaded once per table."""
-        import torch
-        if getattr(self, "_dev", None) is None or self._dev[0] != str(device):
-            up = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.int32))).to(device)
-            self._dev = (str(device), [up(x) for x in (self.off, self.qs, self.qe, self.tid, self.ra, self.rb, self.strand, self.mapq)])
-        return self._dev[1]
 
     @property
     def n_rows(self):
@@ -67,7 +60,7 @@ def build_chimeric_table(dr) -> ChimericTable:
         raise ZeroDivisionError("division by zero")
     _lib.check(rc, "coral_nm_stats")
     T.n_mapq60_plain, T.nm_sum, T.nm_sum_sq = int(cnt.value), float(s0.value), float(s1.value)
-    cols, off, name_id, failed, rl = kernels.sa_table(dr)
+    cols, off, name_id, failed, rl, T.pairs = kernels.sa_table(dr)
     T.read_length = rl
     T.name_id, T.failed, T.off = name_id, failed, off
     T.qs, T.qe, T.tid, T.ra, T.rb, T.strand, T.mapq = (cols[k] for k in range(7))
@@ -110,14 +103,6 @@ class Candidates:
         return Candidates(**{k: np.concatenate([getattr(p, k) for p in parts]) for k in Candidates.FIELDS})
 
 
-def candidates_between(T: ChimericTable, reads: np.ndarray, I1, I2, chr_rank, dr, min_bp_match_cutoff=100, min_mapq=20,
-                       gap_mapq=10) -> Candidates:
-    """alignment2bp (bu:70-96) for ``reads`` (indices into T, in iteration order) between intervals I1 and I2
-    (each (tid, start, end)) — coral_bp_candidates, mode 1."""
-    from . import kernels
-    return kernels.bp_candidates(dr, T, reads, 1, [I1, I2], chr_rank, min_bp_match_cutoff, min_mapq, 100, gap_mapq)
-
-
 def first_interval_overlap(T: ChimericTable, intervals: Sequence[Tuple[int, int, int]]) -> np.ndarray:
     """interval_overlap_l (bu:37-44) for every row: index of the first interval overlapping it, -1 if none."""
     io = np.full(T.n_rows, -1, dtype=np.int64)
@@ -128,8 +113,83 @@ def first_interval_overlap(T: ChimericTable, intervals: Sequence[Tuple[int, int,
     return io
 
 
-def candidates_within(T: ChimericTable, intervals, chr_rank, dr, min_bp_match_cutoff=100, min_mapq=20, gap_=100,
-                      gap_mapq=10) -> Candidates:
-    """alignment2bp_l (bu:129-186) for every chimeric read in dict order — coral_bp_candidates, mode 0."""
-    from . import kernels
-    return kernels.bp_candidates(dr, T, None, 0, list(intervals), chr_rank, min_bp_match_cutoff, min_mapq, gap_, gap_mapq)
+class PairSearch:
+    """Native side of the interval search over one chimeric table (csrc/coral_search.cpp): the reach sets of ibg:369-384
+    replayed as CPython sets, the runs of neighbouring segments, and alignment2bp / alignment2bp_l as a FILTER over the pair
+    table the GPU built once (coral_bp_pair_table).  Every method returns ``Candidates`` with ``read`` = name id."""
+
+    def __init__(self, T: ChimericTable, read_hash: np.ndarray, e_key: np.ndarray, e_row: np.ndarray, seg_off, seg_start, seg_end):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib, self._L = C, _lib, _lib.lib()
+        i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+        # the handle borrows these arrays: keep them alive (and unchanged in place) for its lifetime
+        self._keep = [i64(T.off), i64(T.read), i64(T.tid), i64(T.ra), i64(T.rb), T.cni0, T.cni1, i64(read_hash), i64(T.name_id),
+                      i64(e_key), i64(e_row), np.ascontiguousarray(T.pairs, dtype=np.int32), i64(seg_off), i64(seg_start), i64(seg_end)]
+        assert T.cni0.dtype == np.int64 and T.cni1.dtype == np.int64 and T.cni0.flags.c_contiguous and T.cni1.flags.c_contiguous
+        assert self._keep[11].shape == (2 * T.n_rows, 8), "pair table must hold two slots per table row"
+        k = self._keep
+        ptr = lambda a: a.ctypes.data
+        self._h = self._L.coral_search_create(T.n_reads, T.n_rows, ptr(k[0]), ptr(k[1]), ptr(k[2]), ptr(k[3]), ptr(k[4]), ptr(k[5]),
+                                              ptr(k[6]), ptr(k[7]), ptr(k[8]), len(k[9]), ptr(k[9]), ptr(k[10]), ptr(k[11]),
+                                              len(k[12]) - 1, ptr(k[12]), ptr(k[13]), ptr(k[14]))
+        if not self._h:
+            raise _lib.CoralHipError("coral_search_create failed")
+
+    def close(self):
+        if self._h:
+            self._L.coral_search_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc, what):
+        if rc == -4:                                      # CORAL_ERR_FORMAT: contig outside chr1..22,X,Y,M reaches interval2bp
+            raise KeyError("contig name outside chr1..22,X,Y,M")      # gn:13-18 lookup at bu:293
+        if rc != 0:
+            msg = self._L.coral_search_error(self._h).decode()
+            if "segment index out of range" in msg:
+                raise IndexError("list index out of range")             # by[c][cni] in the reference
+            raise self._lib.CoralHipError("%s failed (%d): %s" % (what, rc, msg))
+
+    def _result(self, want_orders=False):
+        C = self._C
+        ng, nc = C.c_int64(0), C.c_int64(0)
+        gp, cp, oo, op = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.POINTER(C.c_int32)()
+        self._lib.check(self._L.coral_search_result(self._h, C.byref(ng), C.byref(gp), C.byref(nc), C.byref(cp), C.byref(oo),
+                                                    C.byref(op)), "coral_search_result")
+        groups = np.ctypeslib.as_array(gp, shape=(ng.value, 4)).copy() if ng.value else np.zeros((0, 4), dtype=np.int64)
+        rows = np.ctypeslib.as_array(cp, shape=(nc.value, 13)).copy() if nc.value else np.zeros((0, 13), dtype=np.int64)
+        out, at = [], 0
+        for g in range(ng.value):
+            n = int(groups[g, 3])
+            part = rows[at:at + n]
+            out.append(Candidates(**{k: part[:, j] for j, k in enumerate(Candidates.FIELDS)}))
+            at += n
+        orders = [] if want_orders else None
+        if want_orders and ng.value:
+            off = np.ctypeslib.as_array(oo, shape=(ng.value + 1,)).copy()
+            flat = np.ctypeslib.as_array(op, shape=(int(off[-1]),)).copy() if off[-1] else np.zeros(0, dtype=np.int32)
+            orders = [flat[off[g]:off[g + 1]].astype(np.int64) for g in range(ng.value)]
+        return groups, out, orders
+
+    def step(self, tid, s, e, si, ei, min_cluster_cutoff, max_seq_len, want_orders=False):
+        """One step of the interval search for interval (tid, s, e) lying on segments si..ei: (groups int64 [G, 4] =
+        contig id, first segment, last segment, candidates; [Candidates per group]; [read order per group] or None)."""
+        self._check(self._L.coral_search_step(self._h, int(tid), int(s), int(e), int(si), int(ei), float(min_cluster_cutoff),
+                                              int(max_seq_len)), "coral_search_step")
+        return self._result(want_orders)
+
+    def within(self, intervals) -> Candidates:
+        """alignment2bp_l (bu:129-186) of every chimeric read, dict order, against [(tid, start, end)]."""
+        iv = np.ascontiguousarray(np.asarray(intervals, dtype=np.int64).reshape(-1, 3).T)
+        self._check(self._L.coral_search_within(self._h, iv.shape[1], iv[0].ctypes.data, iv[1].ctypes.data, iv[2].ctypes.data),
+                    "coral_search_within")
+        return self._result()[1][0]
+
+    def between(self, reads, I1, I2) -> Candidates:
+        """alignment2bp (bu:70-96) of ``reads`` (table indices, iteration order) between intervals I1 and I2 = (tid, start, end)."""
+        r = np.ascontiguousarray(reads, dtype=np.int32)
+        self._check(self._L.coral_search_between(self._h, len(r), r.ctypes.data, *[int(v) for v in I1], *[int(v) for v in I2]),
+                    "coral_search_between")
+        return self._result()[1][0]

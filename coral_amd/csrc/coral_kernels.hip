@@ -909,170 +909,78 @@ extern "C" int coral_read_counter(const uint32_t *dev_counter, uint32_t *host_va
 }
 
 // ---------------------------------------------------------------------------------------------
-// K4  breakpoint candidates from chimeric alignments (one thread per read, two passes: count -> scan -> write, so the
-//     output order is exactly the reference's: reads in the given order, per read all consecutive-pair candidates then
-//     all skip-one candidates).
-//     mode 0 = alignment2bp_l (/root/reference/src/breakpoint_utilities.py:129-186): both segments in the SAME interval
-//     mode 1 = alignment2bp   (bu:70-96): the two segments fall in the two given intervals, in either order
-//     interval2bp (bu:289-295) canonicalises every candidate.
+// K4  pair table — the breakpoint candidate of EVERY pair of local alignments of every chimeric read, in one launch.
+//
+//     alignment2bp / alignment2bp_l (/root/reference/src/breakpoint_utilities.py:70-96, :129-186) look at the pairs
+//     (k, k + 1) and (k - 1, k + 1) of a read's (qs, qe)-sorted alignments; whether a pair yields a candidate depends on the
+//     amplicon intervals of the moment, but WHAT the candidate is (interval2bp, bu:289-295: canonical end order, the
+//     orientations, the query gap) and every interval-independent test (query gap vs min_bp_match_cutoff, the three MAPQ
+//     thresholds, strand change, the |gr - grr| > max(gap_, |0.2 gr|) test of alignment2bp_l) is a pure function of the
+//     two table rows.  So the table is built once per graph build, directly from coral_sa_table's device rows, and the
+//     interval search only filters it (coral_search_step / coral_search_within, host side, no launches, no syncs).
+//
+//     Layout: slot 2 * g + kind for table row g; kind 0 = pair (g, g + 1), kind 1 = pair (g - 1, g + 1) ("skip one", centre g).
+//     One thread per read writes the slots of all its rows (32 bytes per slot, two dwordx4 stores); slots whose pair leaves
+//     the read have bits == 0.  No per-read limit on the number of alignments.
 // ---------------------------------------------------------------------------------------------
-struct CandParams {
-    int n_sel;
-    const int32_t *sel;
-    const int32_t *off, *qs, *qe, *tid, *ra, *rb, *strand, *mapq;
-    int mode, n_int;
-    const int32_t *int_tid, *int_start, *int_end;
-    const int32_t *chr_rank;
-    int n_tid;
-    int cutoff, min_mapq, gap_, gap_mapq;
+struct PairRow {
+    int32_t c1, p1, c2, p2, gap, bits, a, b;
 };
 
-__device__ __forceinline__ bool row_overlaps(const CandParams &P, int row, int t, int s, int e) {
-    // interval_overlap(rint, [chr, s, e]) with rint = [chr, ra, rb]: for '-' rows ra > rb (bu:11-15, Appendix A Q1)
-    return P.tid[row] == t && P.ra[row] <= e && s <= P.rb[row];
+__device__ __forceinline__ PairRow make_pair(const int32_t *__restrict__ rows, int a, int b, int mid, bool skip,
+                                             const int32_t *__restrict__ chr_rank, int n_tid, int cutoff, int min_mapq,
+                                             int gap_, int gap_mapq) {
+    const int32_t *ra_ = rows + 8ll * a, *rb_ = rows + 8ll * b;
+    const int qe_a = ra_[1], tid_a = ra_[2], A_ra = ra_[3], A_rb = ra_[4], st_a = ra_[5], mq_a = ra_[6];
+    const int qs_b = rb_[0], tid_b = rb_[2], B_ra = rb_[3], B_rb = rb_[4], st_b = rb_[5], mq_b = rb_[6];
+    const int gap = qs_b - qe_a;
+    bool ok = mq_a >= min_mapq && mq_b >= min_mapq;
+    if (skip) ok = ok && rows[8ll * mid + 6] < gap_mapq;
+    else ok = ok && (gap + cutoff >= 0);
+    const int c1r = (tid_a >= 0 && tid_a < n_tid) ? chr_rank[tid_a] : -1;
+    const int c2r = (tid_b >= 0 && tid_b < n_tid) ? chr_rank[tid_b] : -1;
+    const bool first_form = (c2r < c1r) || (c2r == c1r && B_ra < A_rb);
+    // alignment2bp_l's distance test for same-strand pairs (bu:145-160, :173-184)
+    const int grr = (st_b == 0) ? (B_ra - A_rb) : (A_rb - B_ra);
+    const long long d = (long long)gap - (long long)grr;
+    const double lim = fmax((double)gap_, fabs((double)gap * 0.2));
+    const bool far = (double)(d < 0 ? -d : d) > lim;
+    PairRow r;
+    int o1, o2;
+    if (first_form) { r.c1 = tid_a; r.p1 = A_rb; o1 = st_a; r.c2 = tid_b; r.p2 = B_ra; o2 = 1 - st_b; }
+    else { r.c1 = tid_b; r.p1 = B_ra; o1 = 1 - st_b; r.c2 = tid_a; r.p2 = A_rb; o2 = st_a; }
+    r.gap = gap;
+    r.bits = 1 | (ok ? 2 : 0) | (o1 << 2) | (o2 << 3) | (first_form ? 0 : 16) | (st_a != st_b ? 32 : 0) | (far ? 64 : 0) |
+             ((c1r < 0 || c2r < 0) ? 128 : 0) | ((mq_a & 0xff) << 8) | ((mq_b & 0xff) << 16);
+    r.a = a;
+    r.b = b;
+    return r;
 }
 
-__device__ __forceinline__ int first_interval(const CandParams &P, int row) {
-    for (int k = 0; k < P.n_int; ++k)
-        if (row_overlaps(P, row, P.int_tid[k], P.int_start[k], P.int_end[k])) return k;
-    return -1;
+__global__ __launch_bounds__(256) void k_bp_pairs(int n_reads, const int32_t *__restrict__ off, const int32_t *__restrict__ rows,
+                                                  const int32_t *__restrict__ chr_rank, int n_tid, int cutoff, int min_mapq,
+                                                  int gap_, int gap_mapq, PairRow *__restrict__ out) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_reads) return;
+    const int base = off[r], n = off[r + 1] - base;
+    const PairRow none = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < n; ++k) {
+        const int g = base + k;
+        out[2ll * g] = (k + 1 < n) ? make_pair(rows, g, g + 1, g, false, chr_rank, n_tid, cutoff, min_mapq, gap_, gap_mapq) : none;
+        out[2ll * g + 1] = (k >= 1 && k + 1 < n) ? make_pair(rows, g - 1, g + 1, g, true, chr_rank, n_tid, cutoff, min_mapq, gap_, gap_mapq) : none;
+    }
 }
 
-__device__ __forceinline__ bool pair_qualifies(const CandParams &P, int a, int b, int sel_index) {
-    if (P.mode == 1 || P.mode == 2) {
-        // mode 1: the two intervals are [0] and [1]; mode 2 (several mode-1 queries in one launch): the selection carries an
-        // interval index per read after the read indices, and every read pairs that interval with the LAST one
-        const int k1 = P.mode == 1 ? 0 : P.sel[P.n_sel + sel_index];
-        const int k2 = P.mode == 1 ? 1 : P.n_int - 1;
-        const bool a1 = row_overlaps(P, a, P.int_tid[k1], P.int_start[k1], P.int_end[k1]);
-        const bool a2 = row_overlaps(P, a, P.int_tid[k2], P.int_start[k2], P.int_end[k2]);
-        const bool b1 = row_overlaps(P, b, P.int_tid[k1], P.int_start[k1], P.int_end[k1]);
-        const bool b2 = row_overlaps(P, b, P.int_tid[k2], P.int_start[k2], P.int_end[k2]);
-        return (a1 && b2) || (b1 && a2);
-    }
-    const int ia = first_interval(P, a), ib = first_interval(P, b);
-    if (ia < 0 || ib < 0 || ia != ib) return false;
-    if (P.strand[a] != P.strand[b]) return true;
-    const int gr = P.qs[b] - P.qe[a];
-    const int grr = (P.strand[b] == 0) ? (P.ra[b] - P.rb[a]) : (P.rb[a] - P.ra[b]);
-    const long long d = (long long)gr - (long long)grr;
-    const double lim = fmax((double)P.gap_, fabs((double)gr * 0.2));
-    return (double)(d < 0 ? -d : d) > lim;
-}
-
-__device__ __forceinline__ void emit_candidate(const CandParams &P, int a, int b, int ia, int ib, int read, int32_t *__restrict__ out,
-                                               int32_t *__restrict__ err) {
-    const int c1r = P.chr_rank[P.tid[a]], c2r = P.chr_rank[P.tid[b]];
-    if (c1r < 0 || c2r < 0) *err = 1;                                   // contig outside chr1..22,X,Y,M (KeyError in the reference)
-    const bool first_form = (c2r < c1r) || (c2r == c1r && P.ra[b] < P.rb[a]);
-    const int gap = P.qs[b] - P.qe[a];
-    if (first_form) {
-        out[0] = P.tid[a]; out[1] = P.rb[a]; out[2] = P.strand[a];
-        out[3] = P.tid[b]; out[4] = P.ra[b]; out[5] = 1 - P.strand[b];
-        out[7] = ia; out[8] = ib; out[10] = 0;
-    } else {
-        out[0] = P.tid[b]; out[1] = P.ra[b]; out[2] = 1 - P.strand[b];
-        out[3] = P.tid[a]; out[4] = P.rb[a]; out[5] = P.strand[a];
-        out[7] = ib; out[8] = ia; out[10] = 1;
-    }
-    out[6] = read; out[9] = gap; out[11] = P.mapq[a]; out[12] = P.mapq[b];
-}
-
-template <bool WRITE>
-__global__ __launch_bounds__(256) void k_bp_candidates(CandParams P, int32_t *__restrict__ counts, int32_t *__restrict__ cand, int cap) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P.n_sel) return;
-    const int read = P.sel ? P.sel[i] : i;
-    const int base = P.off[read], n = P.off[read + 1] - base;
-    int32_t *err = counts + P.n_sel + 1;
-    if (n > 64) { *err = 2; if (!WRITE) counts[i] = 0; return; }
-    int w = WRITE ? counts[i] : 0;          // write cursor (exclusive prefix) / running count
-    unsigned long long used = 0ull;
-    for (int k = 0; k + 1 < n; ++k) {
-        const int a = base + k, b = a + 1;
-        const int gap = P.qs[b] - P.qe[a];
-        if (gap + P.cutoff >= 0 && P.mapq[a] >= P.min_mapq && P.mapq[b] >= P.min_mapq && pair_qualifies(P, a, b, i)) {
-            used |= 1ull << k;
-            if (WRITE) { if (w < cap) emit_candidate(P, a, b, k, k + 1, read, cand + (long long)w * 13, err); }
-            ++w;
-        }
-    }
-    for (int k = 1; k + 1 < n; ++k) {
-        const int a = base + k - 1, m = base + k, b = base + k + 1;
-        if (((used >> (k - 1)) & 1ull) || ((used >> k) & 1ull)) continue;
-        if (!(P.mapq[m] < P.gap_mapq && P.mapq[a] >= P.min_mapq && P.mapq[b] >= P.min_mapq)) continue;
-        if (pair_qualifies(P, a, b, i)) {
-            if (WRITE) { if (w < cap) emit_candidate(P, a, b, k - 1, k + 1, read, cand + (long long)w * 13, err); }
-            ++w;
-        }
-    }
-    if (!WRITE) counts[i] = w;
-}
-
-// exclusive prefix sum of counts[0..n) in place, total into counts[n]; one workgroup (n is the number of chimeric reads)
-__global__ __launch_bounds__(1024) void k_exclusive_scan_i32(int32_t *__restrict__ v, int n) {
-    __shared__ int part[1024];
-    const int t = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int a = min(n, t * per), b = min(n, a + per);
-    int s = 0;
-    for (int i = a; i < b; ++i) s += v[i];
-    part[t] = s;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const int x = (t >= d) ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += x;
-        __syncthreads();
-    }
-    int run = part[t] - s;
-    for (int i = a; i < b; ++i) {
-        const int x = v[i];
-        v[i] = run;
-        run += x;
-    }
-    if (t == 1023) v[n] = part[1023];
-}
-
-extern "C" int coral_bp_candidates(const coral_chimeric_t *ct, int32_t n_sel, const int32_t *sel, int32_t mode, int32_t n_int,
-                                   const int32_t *int_tid, const int32_t *int_start, const int32_t *int_end,
+extern "C" int coral_bp_pair_table(int32_t n_reads, int32_t n_rows, const int32_t *off, const int32_t *rows,
                                    const int32_t *chr_rank, int32_t n_tid, int32_t min_bp_match_cutoff, int32_t min_mapq,
-                                   int32_t gap_, int32_t gap_mapq, int32_t *counts, int32_t *cand, int32_t cap,
-                                   int32_t *n_out, void *stream) {
-    if (!ct || !n_out || n_sel < 0) return set_err(CORAL_ERR_ARG, "bp_candidates: bad arguments");
-    *n_out = 0;
-    if (n_sel == 0) return CORAL_OK;
-    if (!ct->off || !ct->qs || !ct->qe || !ct->tid || !ct->ra || !ct->rb || !ct->strand || !ct->mapq || !counts || !chr_rank ||
-        !int_tid || !int_start || !int_end || (cap > 0 && !cand))
-        return set_err(CORAL_ERR_ARG, "bp_candidates: null argument");
-    if (mode == 1 && n_int != 2) return set_err(CORAL_ERR_ARG, "bp_candidates: mode 1 needs exactly two intervals");
-    if (mode == 2 && (n_int < 2 || !sel)) return set_err(CORAL_ERR_ARG, "bp_candidates: mode 2 needs a selection (reads, then interval index per read) and >= 2 intervals");
-    if (mode < 0 || mode > 2) return set_err(CORAL_ERR_ARG, "bp_candidates: unknown mode");
-    if (!sel && n_sel != ct->n_reads) return set_err(CORAL_ERR_ARG, "bp_candidates: sel == NULL means all reads");
-    CandParams P;
-    P.n_sel = n_sel; P.sel = sel;
-    P.off = ct->off; P.qs = ct->qs; P.qe = ct->qe; P.tid = ct->tid; P.ra = ct->ra; P.rb = ct->rb; P.strand = ct->strand; P.mapq = ct->mapq;
-    P.mode = mode; P.n_int = n_int; P.int_tid = int_tid; P.int_start = int_start; P.int_end = int_end;
-    P.chr_rank = chr_rank; P.n_tid = n_tid;
-    P.cutoff = min_bp_match_cutoff; P.min_mapq = min_mapq; P.gap_ = gap_; P.gap_mapq = gap_mapq;
-    hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(counts + n_sel, 0, 2 * sizeof(int32_t), s);
-    if (e != hipSuccess) return hip_err(e, "bp_candidates memset");
-    const int blocks = (n_sel + 255) / 256;
-    hipLaunchKernelGGL(k_bp_candidates<false>, dim3(blocks), dim3(256), 0, s, P, counts, cand, (int)cap);
-    hipLaunchKernelGGL(k_exclusive_scan_i32, dim3(1), dim3(1024), 0, s, counts, (int)n_sel);
-    int32_t tail[2] = {0, 0};
-    e = hipMemcpyAsync(tail, counts + n_sel, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) return hip_err(e, "bp_candidates count");
-    *n_out = tail[0];
-    if (tail[1] == 2) return set_err(CORAL_ERR_ARG, "bp_candidates: a read has more than 64 local alignments");
-    if (tail[0] > cap) return set_err(CORAL_ERR_CAPACITY, "bp_candidates: candidate buffer too small");
-    if (tail[0] == 0) return CORAL_OK;
-    hipLaunchKernelGGL(k_bp_candidates<true>, dim3(blocks), dim3(256), 0, s, P, counts, cand, (int)cap);
-    e = hipMemcpyAsync(tail, counts + n_sel, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) return hip_err(e, "bp_candidates write");
-    if (tail[1] == 1) return set_err(CORAL_ERR_FORMAT, "bp_candidates: contig outside chr1..22,X,Y,M");
+                                   int32_t gap_, int32_t gap_mapq, int32_t *pairs, void *stream) {
+    if (n_reads < 0 || n_rows < 0 || n_tid < 0) return set_err(CORAL_ERR_ARG, "bp_pair_table: negative size");
+    if (n_reads == 0 || n_rows == 0) return CORAL_OK;
+    if (!off || !rows || !chr_rank || !pairs) return set_err(CORAL_ERR_ARG, "bp_pair_table: null argument");
+    if (((uintptr_t)pairs) & 15u) return set_err(CORAL_ERR_ARG, "bp_pair_table: pairs must be 16-byte aligned");
+    hipLaunchKernelGGL(k_bp_pairs, dim3((n_reads + 255) / 256), dim3(256), 0, (hipStream_t)stream, (int)n_reads, off, rows, chr_rank,
+                       (int)n_tid, (int)min_bp_match_cutoff, (int)min_mapq, (int)gap_, (int)gap_mapq, reinterpret_cast<PairRow *>(pairs));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_err(e, "bp_pair_table launch");
     return CORAL_OK;
 }

@@ -15,7 +15,6 @@
 
 #include "../../include/coral_hip.h"
 
-#define MAX_SEGS 64
 #define INVALID_KEY 0x7fffffff
 
 static thread_local char g_sa_err[256] = "";
@@ -81,9 +80,9 @@ __device__ __forceinline__ void parse_row(const int32_t *__restrict__ f, int nm,
 __global__ void k_group_process(int n_groups, const int32_t *__restrict__ gstart, const int32_t *__restrict__ keys,
                                 const int32_t *__restrict__ vals, const int32_t *__restrict__ sa,
                                 const int32_t *__restrict__ sa_nm, const int32_t *__restrict__ first_primary,
-                                const int32_t *__restrict__ rec_qlen, int32_t *__restrict__ tmp_rows /* [n_sa][8] */,
-                                int32_t *__restrict__ n_kept, int32_t *__restrict__ g_first, int32_t *__restrict__ g_failed,
-                                int32_t *__restrict__ err) {
+                                const int32_t *__restrict__ rec_qlen, int32_t *__restrict__ kept_ws /* [n_sa] */,
+                                int32_t *__restrict__ tmp_rows /* [n_sa][8] */, int32_t *__restrict__ n_kept,
+                                int32_t *__restrict__ g_first, int32_t *__restrict__ g_failed, int32_t *__restrict__ err) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_groups) return;
     const int a = gstart[g], b = gstart[g + 1];
@@ -96,8 +95,10 @@ __global__ void k_group_process(int n_groups, const int32_t *__restrict__ gstart
     if (fp == INVALID_KEY) return;                       // chimeric read without a primary alignment: dropped (ibg:163-173)
     g_first[g] = vals[a];                                // stable sort: the read's first SA row in file order
     const int rl = rec_qlen[fp];
+    // The group owns slots a..b of kept_ws and tmp_rows (it has b - a SA rows), so a read may have any number of
+    // alignments: nothing is kept in per-thread arrays.
     // first-seen de-duplication (ibg:146-151), then cp:246-255: the read fails as a whole at its first offending entry
-    int kept_idx[MAX_SEGS];
+    int32_t *__restrict__ kept_idx = kept_ws + a;
     int nk = 0;
     for (int i = a; i < b; ++i) {
         const int32_t *fi = sa + 8ll * vals[i];
@@ -110,7 +111,6 @@ __global__ void k_group_process(int n_groups, const int32_t *__restrict__ gstart
             dup = same;
         }
         if (dup) continue;
-        if (nk >= MAX_SEGS) { atomicMax(err, 2); return; }
         kept_idx[nk++] = vals[i];
     }
     for (int j = 0; j < nk; ++j) {
@@ -118,23 +118,20 @@ __global__ void k_group_process(int n_groups, const int32_t *__restrict__ gstart
         if (f[3] == -2) { atomicMax(err, 3); return; }                       // unknown shape: KeyError in the reference
         if ((f[3] <= 0 && f[6] <= 0) || f[4] <= 0) { g_failed[g] = 1; return; }   // no S or no M: ([], [], [])
     }
-    // parse + stable insertion sort by (qs, qe) (cp:263)
-    ParsedRow rows[MAX_SEGS];
+    // parse + stable insertion sort by (qs, qe) (cp:263), in place in the group's slots of tmp_rows
+    ParsedRow *__restrict__ rows = reinterpret_cast<ParsedRow *>(tmp_rows + 8ll * a);
     for (int j = 0; j < nk; ++j) {
         ParsedRow p;
         parse_row(sa + 8ll * kept_idx[j], sa_nm[kept_idx[j]], rl, p);
         if (p.qe == p.qs) atomicMax(err, 4);                                  // ZeroDivisionError at cp:268
         int k = j;
-        while (k > 0 && (rows[k - 1].qs > p.qs || (rows[k - 1].qs == p.qs && rows[k - 1].qe > p.qe))) {
-            rows[k] = rows[k - 1];
+        while (k > 0) {
+            const ParsedRow q = rows[k - 1];
+            if (!(q.qs > p.qs || (q.qs == p.qs && q.qe > p.qe))) break;
+            rows[k] = q;
             --k;
         }
         rows[k] = p;
-    }
-    for (int j = 0; j < nk; ++j) {
-        int32_t *o = tmp_rows + 8ll * (a + j);
-        o[0] = rows[j].qs; o[1] = rows[j].qe; o[2] = rows[j].tid; o[3] = rows[j].ra; o[4] = rows[j].rb;
-        o[5] = rows[j].strand; o[6] = rows[j].mapq; o[7] = rows[j].nm;
     }
     n_kept[g] = nk;
 }
@@ -209,7 +206,7 @@ extern "C" int coral_sa_table(int32_t n_rec, const int32_t *rec_tid, const int32
     {
         char *p = nullptr;
         carve<char>(p, cub_bytes);
-        for (int k = 0; k < 12; ++k) carve<int32_t>(p, ns + 2);
+        for (int k = 0; k < 13; ++k) carve<int32_t>(p, ns + 2);
         carve<int32_t>(p, 8 * ns);
         carve<int32_t>(p, (size_t)n_names + 1);
         need = (size_t)p;
@@ -224,7 +221,8 @@ extern "C" int coral_sa_table(int32_t n_rec, const int32_t *rec_tid, const int32
     int32_t *keys = carve<int32_t>(p, ns + 2), *vals = carve<int32_t>(p, ns + 2), *keys_s = carve<int32_t>(p, ns + 2),
             *vals_s = carve<int32_t>(p, ns + 2), *head = carve<int32_t>(p, ns + 2), *gid = carve<int32_t>(p, ns + 2),
             *gstart = carve<int32_t>(p, ns + 2), *n_kept = carve<int32_t>(p, ns + 2), *g_first = carve<int32_t>(p, ns + 2),
-            *g_failed = carve<int32_t>(p, ns + 2), *g_ids = carve<int32_t>(p, ns + 2), *scratch = carve<int32_t>(p, ns + 2);
+            *g_failed = carve<int32_t>(p, ns + 2), *g_ids = carve<int32_t>(p, ns + 2), *scratch = carve<int32_t>(p, ns + 2),
+            *kept_ws = carve<int32_t>(p, ns + 2);
     int32_t *tmp_rows = carve<int32_t>(p, 8 * ns);
     int32_t *first_primary = carve<int32_t>(p, (size_t)n_names + 1);
     const int B = 256;
@@ -256,7 +254,7 @@ extern "C" int coral_sa_table(int32_t n_rec, const int32_t *rec_tid, const int32
     if (e != hipSuccess) return sa_err(CORAL_ERR_HIP, hipGetErrorString(e));
     const int GG = (n_groups + B - 1) / B;
     hipLaunchKernelGGL(k_group_process, dim3(GG), dim3(B), 0, s, n_groups, gstart, keys_s, vals_s, sa, sa_nm, first_primary,
-                       rec_qlen, tmp_rows, n_kept, g_first, g_failed, err);
+                       rec_qlen, kept_ws, tmp_rows, n_kept, g_first, g_failed, err);
     // ---- reads in the reference's dict order = by first SA-bearing record = by their first SA row
     hipLaunchKernelGGL(k_iota, dim3(GG), dim3(B), 0, s, n_groups, g_ids);
     int32_t *gf_sorted = keys, *g_sorted = vals;          // the unsorted row keys are no longer needed
@@ -276,7 +274,6 @@ extern "C" int coral_sa_table(int32_t n_rec, const int32_t *rec_tid, const int32
     if (e == hipSuccess) e = hipMemcpyAsync(&n_rows, off + n_groups, sizeof(int32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return sa_err(CORAL_ERR_HIP, hipGetErrorString(e));
-    if (h[0] == 2) return sa_err(CORAL_ERR_ARG, "sa_table: a read has more than 64 distinct SA entries");
     if (h[0] == 3) return sa_err(CORAL_ERR_FORMAT, "sa_table: SA CIGAR shape outside SM/MS/SMS/SMD/MDS/SMDS/SMI/MIS/SMIS");
     if (h[0] == 4) return sa_err(CORAL_ERR_ZERODIV, "sa_table: zero-length query interval (ZeroDivisionError in the reference)");
     const int n_reads = h[1];

@@ -29,17 +29,16 @@ from typing import Dict, Optional
 
 import numpy as np
 
-import ctypes as C
 import os
 import weakref
-from concurrent.futures import ThreadPoolExecutor
 
 from . import _lib, global_names, kernels
 from . import _pyobjects          # CPython extension built by __graft_entry__.build(); no Python fallback
 from .bpcluster import call_breakpoints
 from .breakpoint_graph import BreakpointGraph, compute_cn_lr, output_breakpoint_graph_lr, output_breakpoint_info_lr
-from .chimeric import Candidates, ChimericTable, build_chimeric_table, candidates_within
+from .chimeric import Candidates, ChimericTable, PairSearch, build_chimeric_table
 from .global_names import chr_idx
+from .lazysets import ReadNameSet, ReadSupportSet
 
 _ORI = "+-"
 _VERIFY_SET_ORDER = os.environ.get("CORAL_VERIFY_SET_ORDER") == "1"     # tests: cross-check the set replay against real sets
@@ -211,8 +210,7 @@ class bam_to_breakpoint_nanopore():
         self.normal_cov = 0.0
         self.ccid2id = dict()
         self.new_bp_list = []
-        self._pool, self._ahead = None, {}           # look-ahead of the interval search (find_amplicon_intervals)
-        self._bp_name_ids: Dict[int, list] = {}     # id(support set) -> [name id arrays]; see addbp
+        self._search_ctx: Optional[PairSearch] = None      # native side of the interval search (coral_search_*)
         self.new_bp_stats = []
         self.new_bp_ccids = []
         self.source_edges = []
@@ -227,7 +225,6 @@ class bam_to_breakpoint_nanopore():
         self._hashed = False
         chroms = self.rec.header_chroms
         self._tid_of = {c: k for k, c in enumerate(chroms)}
-        self._chr_rank = np.array([chr_idx.get(c, -1) for c in chroms], dtype=np.int64)
         with open(seedfile, 'r') as fp:
             for line in fp:
                 s = line.strip().split()
@@ -441,28 +438,10 @@ class bam_to_breakpoint_nanopore():
                 iv[2] = by[c][rcni][2] + self.interval_delta
         ccid = 0
         _lib.check_pyset_replay()            # once per process: the set replay must match this interpreter's sets
-        # look-ahead worker for the pure part of every search step (_prepare_step); results are keyed by interval index and
-        # coordinates, so a step is recomputed in line if its interval changed after it was queued (it never does today)
-        self._ahead = {}
-        # a few thousand chimeric reads: thread hand-offs cost more than they hide (threshold overridable for tests)
-        small = len(self._chim.read) < int(os.environ.get("CORAL_AHEAD_MIN_READS", "20000"))
-        self._pool = None if (_VERIFY_SET_ORDER or small) else ThreadPoolExecutor(
-            max_workers=int(os.environ.get("CORAL_AHEAD_THREADS", "2")), thread_name_prefix="coral-ahead",
-            initializer=_bind_thread_to_device, initargs=(self.rec.device,))
-        try:
-            if self._pool is not None and len(self._chim.read):
-                self._read_hashes()                                    # shared caches are filled before the worker starts
-                self._chim.device_arrays(self.rec.device)
-                for ai in range(len(self.amplicon_intervals)):
-                    self._submit_ahead(ai)
-            for ai in range(len(self.amplicon_intervals)):
-                if self.amplicon_intervals[ai][3] == -1:
-                    self.find_interval_i(ai, ccid)
-                    ccid += 1
-        finally:
-            if self._pool is not None:
-                self._pool.shutdown(wait=True, cancel_futures=True)
-            self._pool, self._ahead = None, {}
+        for ai in range(len(self.amplicon_intervals)):
+            if self.amplicon_intervals[ai][3] == -1:
+                self.find_interval_i(ai, ccid)
+                ccid += 1
         logging.debug(_t() + "Identified %d amplicon intervals in total." % len(self.amplicon_intervals))
         self._merge_intervals()
 
@@ -533,24 +512,17 @@ class bam_to_breakpoint_nanopore():
                         queue.append(p)
         logging.debug(_t() + "There are %d amplicon intervals after merging." % len(self.amplicon_intervals))
 
-    def addbp(self, bp_, bpr_, bp_stats_, ccid, name_ids=None):
+    def addbp(self, bp_, bpr_, bp_stats_, ccid):
         """Append a breakpoint, or merge its reads into the first one within 200 bp at both ends (ibg:326-340).
-
-        ``name_ids`` (optional) = name ids of the reads in ``bpr_``; kept beside the set (keyed by the set object, which is the
-        one the graph's discordant edge ends up holding) so that assign_cov can test membership on integer arrays."""
+        ``bpr_``: the supporting (name, i, j) tuples — a ReadSupportSet from this build, or any iterable of tuples."""
         for k, bp in enumerate(self.new_bp_list):
             if bp[0] == bp_[0] and bp[3] == bp_[3] and bp[2] == bp_[2] and bp[5] == bp_[5] and \
                     abs(bp[1] - bp_[1]) < 200 and abs(bp[4] - bp_[4]) < 200:
-                bp[-1] |= set(bpr_)
-                ids = self._bp_name_ids.get(id(bp[-1]))
-                if ids is not None:
-                    if name_ids is None:
-                        del self._bp_name_ids[id(bp[-1])]
-                    else:
-                        ids.append(name_ids)
+                if isinstance(bpr_, ReadSupportSet):
+                    bp[-1] |= bpr_                       # both still arrays: the chunk is appended, nothing is built
+                else:
+                    bp[-1] |= set(bpr_)
                 return k
-        if name_ids is not None:
-            self._bp_name_ids[id(bpr_)] = [name_ids]
         self.new_bp_list.append(bp_ + [bpr_])
         self.new_bp_ccids.append(ccid)
         self.new_bp_stats.append(bp_stats_)
@@ -561,10 +533,9 @@ class bam_to_breakpoint_nanopore():
         """Read-name strings of an array of name ids (coral_amd._pyobjects: one C loop, no per-item interpreter work)."""
         return _pyobjects.names_of(self.rec.names, np.ascontiguousarray(ids, dtype=np.int64))
 
-    def _read_tuples(self, c: Candidates, idx):
-        """[(name, i, j)] of the candidates ``idx`` — the support tuples of bu:81 / ibg:772."""
-        g = lambda a: np.ascontiguousarray(a[idx], dtype=np.int64)
-        return _pyobjects.read_tuples(self.rec.names, g(c.read), g(c.i), g(c.j))
+    def _support(self, c: Candidates, idx) -> ReadSupportSet:
+        """The ``set((name, i, j))`` of the candidates ``idx`` (bu:81 / ibg:772) — as arrays until somebody iterates it."""
+        return ReadSupportSet(self.rec.names, c.read[idx], c.i[idx], c.j[idx])
 
     def _cluster_and_call(self, c: Candidates, advance_subcluster: bool):
         """Native part of _call_breakpoints: (cluster sizes, accepted calls) — a pure function of the candidates."""
@@ -573,7 +544,7 @@ class bam_to_breakpoint_nanopore():
                                 advance_subcluster)
 
     def _call_breakpoints(self, c: Candidates, advance_subcluster: bool, called=None):
-        """Cluster the candidates and yield (bp list, support tuples, stats, name ids) for every accepted (sub)cluster.
+        """Cluster the candidates and yield (bp list, support set, stats) for every accepted (sub)cluster.
 
         ``advance_subcluster`` is False inside the interval BFS, where the reference never increments its
         sub-cluster counter (ibg:442-457, Appendix A Q4), and True in find_breakpoints / find_smalldel_breakpoints.
@@ -587,78 +558,9 @@ class bam_to_breakpoint_nanopore():
         for head, p1, p2, sup, st in calls:
             bp = [chroms[c.c1[head]], p1, _ORI[c.o1[head]], chroms[c.c2[head]], p2, _ORI[c.o2[head]],
                   (self.rec.names[c.read[head]], int(c.i[head]), int(c.j[head])), int(c.gap[head]), int(c.swapped[head])]
-            yield bp, self._read_tuples(c, sup), st, c.read[sup]
+            yield bp, self._support(c, sup), st
 
     # -- BFS helpers ---------------------------------------------------------------------------------
-    def _reachable_segments(self, chrom, si, ei):
-        """CN segments outside [si, ei] reached from it through chimeric reads (ibg:369-384).
-
-        The reference keeps ``{chr: {cni: set(read names)}}``; here every such set exists only as a native replay of the
-        Python set (coral_pyset_*: same insertion sequence, same str hashes), which yields its size and — after the ``|=``
-        unions of ibg:405-419 — its iteration order as read indices, without creating a single Python object per read.
-        Returns (keys, counts, handle): ``keys`` = {chr: {cni: key id}} in the reference's chromosome-key order,
-        ``counts[key id]`` = distinct reads, ``handle`` for ``_iteration_order`` (freed by the caller).
-        """
-        T = self._chim
-        tid = self._tid_of[chrom]
-        if tid not in self._seg_tids:
-            raise KeyError(chrom)                       # self.chimeric_alignments_seg[chr] at ibg:371
-        lo = np.searchsorted(self._e_key, tid * (1 << 32) + si, side="left")
-        hi = np.searchsorted(self._e_key, tid * (1 << 32) + ei + 1, side="left")
-        visit = np.ascontiguousarray(self._e_row[lo:hi])  # visiting order: cni ascending, then append order
-        if len(visit) == 0:
-            return {}, np.zeros(0, dtype=np.int32), None
-        L = _lib.lib()
-        hashes = self._read_hashes()
-        nk = C.c_int32(0)
-        handle = L.coral_reach_create(len(visit), visit.ctypes.data, T.read.ctypes.data, T.off.ctypes.data, T.tid.ctypes.data,
-                                      T.cni0.ctypes.data, T.cni1.ctypes.data, T.n_reads, tid, si, ei, hashes.ctypes.data,
-                                      C.byref(nk))
-        if not handle:
-            raise _lib.CoralHipError("coral_reach_create failed")
-        codes = np.empty(nk.value, dtype=np.int64)
-        counts = np.empty(nk.value, dtype=np.int32)
-        _lib.check(L.coral_reach_keys(handle, codes.ctypes.data, counts.ctypes.data), "coral_reach_keys")
-        chroms = self.rec.header_chroms
-        keys: Dict[str, Dict[int, int]] = {}
-        for k, cde in enumerate(codes.tolist()):
-            keys.setdefault(chroms[cde >> 32], {})[cde & 0xFFFFFFFF] = k
-        if _VERIFY_SET_ORDER:
-            self._verify_reach(tid, si, ei, visit, keys, counts)
-        return keys, counts, handle
-
-    def _verify_reach(self, tid, si, ei, visit, keys, counts):
-        """Tests only: the traversal of ibg:369-384 with real sets of str, compared with the native result."""
-        T = self._chim
-        names, chroms = self._chim_names, self.rec.header_chroms
-        real: Dict[str, Dict[int, set]] = {}
-        done = set()
-        for row in visit.tolist():
-            r = int(T.read[row])
-            if r in done:
-                continue
-            done.add(r)
-            for k in range(int(T.off[r]), int(T.off[r + 1])):
-                cand = []
-                c0, c1, t = int(T.cni0[k]), int(T.cni1[k]), int(T.tid[k])
-                if c0 >= 0:
-                    cand.append(c0)
-                if c1 >= 0 and c1 != c0:
-                    cand.append(c1)
-                for cni in cand:
-                    if t != tid or cni <= si or cni >= ei:
-                        d = real.setdefault(chroms[t], {})
-                        if cni in d:
-                            d[cni].add(names[r])
-                        else:
-                            d[cni] = set([names[r]])
-        assert list(real) == list(keys), "chromosome order of the reachable segments diverged"
-        for c in real:
-            assert set(real[c]) == set(keys[c])
-            for cni, s_ in real[c].items():
-                assert counts[keys[c][cni]] == len(s_)
-        self._verify_sets = real, keys
-
     def _read_hashes(self) -> np.ndarray:
         """hash(read name) of every chimeric read (index = position in the chimeric table), cached per name id."""
         T = self._chim
@@ -677,82 +579,83 @@ class bam_to_breakpoint_nanopore():
             T._hashes = np.ascontiguousarray(hv[ids])
         return T._hashes
 
-    def _iteration_order(self, handle, key_ids, out) -> np.ndarray:
-        """Read indices in the order ``for r in (set() | sets[k0] | sets[k1] | ...)`` would visit them (ibg:405-432).
-        ``out``: int32 scratch of n_reads + 1 entries (owned by the calling thread)."""
-        L = _lib.lib()
-        k = np.ascontiguousarray(np.asarray(key_ids, dtype=np.int32))
-        n = C.c_int32(0)
-        _lib.check(L.coral_pyset_union_order(handle, len(k), k.ctypes.data, out.ctypes.data, C.byref(n)), "coral_pyset_union_order")
-        order = out[:n.value].astype(np.int64)
-        if _VERIFY_SET_ORDER:                      # tests: the replay must equal real sets of str
-            real, keys = self._verify_sets
-            by_id = {kid: real[c][cni] for c in keys for cni, kid in keys[c].items()}
-            acc = set([])
-            for kk in k.tolist():
-                acc |= by_id[kk]
-            assert [self.chimeric_alignments._index[nm] for nm in acc] == order.tolist(), "set-order replay diverged from CPython"
-        return order
-
-    def _prepare_step(self, chrom, s, e):
-        """The part of one step of the interval search that is a pure function of the interval's coordinates (ibg:362-434):
-        reachable segments and their read sets, the runs of neighbouring segments, the iteration order of every run's reads,
-        the breakpoint candidates between each run and the interval (one coral_bp_candidates launch) and their clustering
-        into exact breakpoints (coral_call_breakpoints).  Being pure, it is
-        computed AHEAD of the search on a worker thread as soon as an interval enters the queue (the native calls release the
-        interpreter lock), while the main thread does the order-dependent work of the previous step.
-        Returns ("ok", None | (plan, candidates per run, calls per run)) or ("error", exception to raise where the reference
-        raises)."""
-        try:
+    def _search(self) -> PairSearch:
+        """Native side of the interval search over this build's chimeric table (created after hash_alignment_to_seg)."""
+        if self._search_ctx is None:
+            chroms = self.rec.header_chroms
             by = self.cns_intervals_by_chr
-            T = self._chim
-            try:
-                si = self.pos2cni(chrom, s)[0]
-                ei = self.pos2cni(chrom, e)[0]
-            except Exception:
-                return "ok", None
-            reach, counts, set_handle = self._reachable_segments(chrom, si, ei)
-            try:
-                for c in list(reach):
-                    for j in [j for j in reach[c] if counts[reach[c][j]] < self.min_cluster_cutoff]:
-                        del reach[c][j]
-                    if not reach[c]:
-                        del reach[c]
-                # every (chromosome, run of neighbouring segments) reached from this interval, in the reference's order
-                plan = []
-                for c in reach:
-                    bins = sorted(reach[c])
-                    members, first = [], 0                  # members: key ids whose sets the reference unions with |=
-                    for k in range(len(bins) - 1):
-                        members.append(reach[c][bins[k]])
-                        if bins[k + 1] - bins[k] > 2 or by[c][bins[k + 1]][1] - by[c][bins[k]][2] > self.max_seq_len:
-                            plan.append((c, bins[first], bins[k], members))
-                            first = k + 1
-                            members = []
-                    members.append(reach[c][bins[-1]])
-                    plan.append((c, bins[first], bins[-1], members))
-                buf = np.empty(T.n_reads + 1, dtype=np.int32)
-                orders = [self._iteration_order(set_handle, keys, buf) for (_, _, _, keys) in plan]   # set-of-str order (Q21)
-            finally:
-                if set_handle:
-                    _lib.lib().coral_pyset_batch_free(set_handle)
-            targets = [(self._tid_of[c], by[c][b0][1], by[c][b1][2]) for (c, b0, b1, _) in plan]
-            all_cands = kernels.bp_candidates_grouped(self.rec, T, orders, targets, (self._tid_of[chrom], s, e), self._chr_rank,
-                                                      self.min_bp_match_cutoff_, 20) if plan else []
-            called = []
-            for cands in all_cands:
-                cands.read = T.name_id[cands.read]
-                called.append(self._cluster_and_call(cands, False))
-            return "ok", (plan, all_cands, called)
-        except Exception as exc:                        # noqa: BLE001 — raised by the caller at the reference's point
-            return "error", exc
+            seg_off = np.zeros(len(chroms) + 1, dtype=np.int64)
+            for t, c in enumerate(chroms):
+                seg_off[t + 1] = seg_off[t] + len(by.get(c, ()))
+            seg_start = np.fromiter((v[1] for c in chroms for v in by.get(c, ())), dtype=np.int64, count=int(seg_off[-1]))
+            seg_end = np.fromiter((v[2] for c in chroms for v in by.get(c, ())), dtype=np.int64, count=int(seg_off[-1]))
+            self._search_ctx = PairSearch(self._chim, self._read_hashes(), self._e_key, self._e_row, seg_off, seg_start, seg_end)
+        return self._search_ctx
 
-    def _submit_ahead(self, idx):
-        if self._pool is not None:
-            coords = tuple(self.amplicon_intervals[idx][:3])
-            old = self._ahead.get(idx)
-            if old is None or old[0] != coords:
-                self._ahead[idx] = (coords, self._pool.submit(self._prepare_step, *coords))
+    def _search_step(self, chrom, s, e):
+        """The part of one step of the interval search that is a pure function of the interval's coordinates (ibg:362-434):
+        reachable segments and their read sets, the runs of neighbouring segments, the iteration order of every run's reads and
+        the breakpoint candidates between each run and the interval — ONE native call (coral_search_step) that replays the
+        reference's sets of read names on index arrays and filters the GPU-built pair table; then the clustering of every
+        run's candidates into exact breakpoints (coral_call_breakpoints).  Returns None (nothing reachable / interval off
+        the CN segments) or (plan [(chr, first segment, last segment)], candidates per run, calls per run)."""
+        try:
+            si = self.pos2cni(chrom, s)[0]
+            ei = self.pos2cni(chrom, e)[0]
+        except Exception:
+            return None
+        tid = self._tid_of[chrom]
+        if tid not in self._seg_tids:
+            raise KeyError(chrom)                       # self.chimeric_alignments_seg[chr] at ibg:371
+        groups, all_cands, orders = self._search().step(tid, s, e, si, ei, self.min_cluster_cutoff, self.max_seq_len,
+                                                        want_orders=_VERIFY_SET_ORDER)
+        chroms = self.rec.header_chroms
+        plan = [(chroms[int(g[0])], int(g[1]), int(g[2])) for g in groups]
+        if _VERIFY_SET_ORDER:
+            self._verify_step(tid, si, ei, plan, orders)
+        called = [self._cluster_and_call(c, False) for c in all_cands]
+        return plan, all_cands, called
+
+    def _verify_step(self, tid, si, ei, plan, orders):
+        """Tests only (CORAL_VERIFY_SET_ORDER=1): ibg:369-419 with REAL sets of str; the native step must give the same runs
+        and, for every run, the same iteration order of the united set."""
+        T = self._chim
+        names, chroms, by = self._chim_names, self.rec.header_chroms, self.cns_intervals_by_chr
+        lo = np.searchsorted(self._e_key, tid * (1 << 32) + si, side="left")
+        hi = np.searchsorted(self._e_key, tid * (1 << 32) + ei + 1, side="left")
+        real: Dict[str, Dict[int, set]] = {}
+        done = set()
+        for row in self._e_row[lo:hi].tolist():
+            r = int(T.read[row])
+            if r in done:
+                continue
+            done.add(r)
+            for k in range(int(T.off[r]), int(T.off[r + 1])):
+                c0, c1, t = int(T.cni0[k]), int(T.cni1[k]), int(T.tid[k])
+                for cni in ([c0] if c0 >= 0 else []) + ([c1] if c1 >= 0 and c1 != c0 else []):
+                    if t != tid or cni <= si or cni >= ei:
+                        d = real.setdefault(chroms[t], {})
+                        if cni in d:
+                            d[cni].add(names[r])
+                        else:
+                            d[cni] = set([names[r]])
+        want = []
+        for c in real:
+            bins = sorted(j for j in real[c] if not len(real[c][j]) < self.min_cluster_cutoff)
+            if not bins:
+                continue
+            first, acc = 0, set([])
+            for k in range(len(bins) - 1):
+                acc |= real[c][bins[k]]
+                if bins[k + 1] - bins[k] > 2 or by[c][bins[k + 1]][1] - by[c][bins[k]][2] > self.max_seq_len:
+                    want.append(((c, bins[first], bins[k]), list(acc)))
+                    first, acc = k + 1, set([])
+            acc |= real[c][bins[-1]]
+            want.append(((c, bins[first], bins[-1]), list(acc)))
+        assert [w[0] for w in want] == plan, "runs of reachable segments diverged from the reference's"
+        index = self.chimeric_alignments._index
+        for (_, members), got in zip(want, orders):
+            assert [index[nm] for nm in members] == got.tolist(), "set-order replay diverged from CPython"
 
     def find_interval_i(self, ai, ccid):
         """Breadth-first search for intervals connected to interval ``ai`` by breakpoint edges (ibg:343-673)."""
@@ -761,34 +664,26 @@ class bam_to_breakpoint_nanopore():
         D = self.interval_delta
         T = self._chim
         queue = [ai]
-        ahead = self._ahead                     # interval index -> (coordinates, future of _prepare_step); see find_amplicon_intervals
-        self._submit_ahead(ai)
         while queue:
             cur = queue.pop(0)
             chrom, s, e = self.amplicon_intervals[cur][:3]
             if self.amplicon_intervals[cur][3] == -1:
                 self.amplicon_intervals[cur][3] = ccid
             logging.debug(_t() + "\t\tNext amplicon interval %d: %s." % (cur, self.amplicon_intervals[cur]))
-            entry = ahead.get(cur)
-            if entry is not None and entry[0] == (chrom, s, e):
-                status, prepared = entry[1].result()
-            else:
-                status, prepared = self._prepare_step(chrom, s, e)
-            if status == "error":
-                raise prepared
+            prepared = self._search_step(chrom, s, e)
             if prepared is None:
                 continue
             plan, all_cands, called = prepared
             here = self.amplicon_intervals[cur]            # not modified before all groups are done (ibg:385-612)
             refined, refined_bps = [], []
-            for gi, (c, b0, b1, _) in enumerate(plan):
+            for gi, (c, b0, b1) in enumerate(plan):
                 ns, ne = by[c][b0][1], by[c][b1][2]
                 tgt = [c, ns, ne]
                 cands = all_cands[gi]
                 logging.debug(_t() + "\t\tFound %d reads connecting the two intervals." % len(cands))
                 found = []
-                for bp, tuples, st, ids in self._call_breakpoints(cands, advance_subcluster=False, called=called[gi]):
-                    k = self.addbp(bp, set(tuples), st, ccid, ids)
+                for bp, support, st in self._call_breakpoints(cands, advance_subcluster=False, called=called[gi]):
+                    k = self.addbp(bp, support, st, ccid)
                     if k not in found:
                         found.append(k)
                 inside, outside = [], []
@@ -918,7 +813,6 @@ class bam_to_breakpoint_nanopore():
                     for o in hit:
                         if o != cur and self.amplicon_intervals[o][3] < 0:
                             queue.append(o)
-                            self._submit_ahead(o)
                 else:
                     for part in parts:
                         nai = len(self.amplicon_intervals)
@@ -937,16 +831,15 @@ class bam_to_breakpoint_nanopore():
                                 else:
                                     conn[(cur, nai)].add(k)
                         queue.append(nai)
-                        self._submit_ahead(nai)
 
     def _add_clustered(self, cands: Candidates):
         """Tail shared by find_breakpoints and find_smalldel_breakpoints (ibg:691-718, ibg:775-802)."""
-        for bp, tuples, st, ids in self._call_breakpoints(cands, advance_subcluster=True):
+        for bp, support, st in self._call_breakpoints(cands, advance_subcluster=True):
             io1 = interval_overlap_l([bp[0], bp[1], bp[1]], self.amplicon_intervals)
             io2 = interval_overlap_l([bp[3], bp[4], bp[4]], self.amplicon_intervals)
             if io1 >= 0 and io2 >= 0:
                 assert self.amplicon_intervals[io1][3] == self.amplicon_intervals[io2][3]
-                k = self.addbp(bp, set(tuples), st, self.amplicon_intervals[io1][3], ids)
+                k = self.addbp(bp, support, st, self.amplicon_intervals[io1][3])
                 self.amplicon_interval_connections.setdefault((min(io1, io2), max(io1, io2)), set()).add(k)
 
     # ---- A6 ----------------------------------------------------------------------------------
@@ -1001,8 +894,7 @@ class bam_to_breakpoint_nanopore():
         """Breakpoints from chimeric alignments inside the amplicon intervals (ibg:676-718)."""
         T = self._chim
         ivs = [(self._tid_of[iv[0]], iv[1], iv[2]) for iv in self.amplicon_intervals]
-        cands = candidates_within(T, ivs, self._chr_rank, self.rec, self.min_bp_match_cutoff_, 20, 100)
-        cands.read = T.name_id[cands.read]
+        cands = self._search().within(ivs)              # alignment2bp_l as a filter over the pair table (cutoffs 100 / 20 / 100 / 10)
         logging.debug(_t() + "Found %d reads with new breakpoints." % (len(cands)))
         self._add_clustered(cands)
 
@@ -1090,24 +982,27 @@ class bam_to_breakpoint_nanopore():
             pts += [(t1, e[1]), (t2, e[4]), (t1, e[1] - cut - 1), (t2, e[4] + cut)]
         cover = kernels.point_cover(self.rec, pts) if pts else []
         nid = self.rec.h_name_id
-        edge_names: Dict[int, set] = {}            # read names of a support set without name ids (membership tests only)
+        names = self.rec.names
+        n_names = self.rec.n_names
+        is_bp_read = np.zeros(n_names, dtype=bool)                  # scratch: reads supporting a discordant edge at either node
         for q, (g, e) in enumerate(edges):
-            rls, rrs, rls1, rrs1 = (np.unique(nid[cover[4 * q + d]]) for d in range(4))
-            support = [g.discordant_edges[k][10] for node in ((e[0], e[1], e[2]), (e[3], e[4], e[5])) for k in g.nodes[node][2]]
+            left, right = nid[cover[4 * q]], nid[cover[4 * q + 1]]    # fetch order (record ordinals ascending)
+            rls, rrs, rls1, rrs1 = np.unique(left), np.unique(right), np.unique(nid[cover[4 * q + 2]]), np.unique(nid[cover[4 * q + 3]])
             both = np.intersect1d(np.intersect1d(rls, rrs, assume_unique=True),
                                   np.intersect1d(rls1, rrs1, assume_unique=True), assume_unique=True)
-            e[9] = set(self._names_of(np.union1d(rls, rrs)))
-            id_lists = [self._bp_name_ids.get(id(s_)) for s_ in support]
+            e[9] = ReadNameSet(names, left, right)                    # rls | rrs (ibg:1054) — name strings only on demand
+            support = [g.discordant_edges[k][10] for node in ((e[0], e[1], e[2]), (e[3], e[4], e[5])) for k in g.nodes[node][2]]
             if not support:
                 e[8] = int(len(both))
-            elif all(x is not None for x in id_lists):        # name ids of every supporting set are at hand
-                e[8] = int(len(both) - np.isin(both, np.concatenate([a for x in id_lists for a in x])).sum())
-            else:
-                rbps = set()
-                for s_ in support:
-                    if id(s_) not in edge_names:
-                        edge_names[id(s_)] = {t[0] for t in s_}
-                    rbps |= edge_names[id(s_)]
+                continue
+            id_arrays = [s_.name_ids() if isinstance(s_, ReadSupportSet) else None for s_ in support]
+            if all(a is not None for a in id_arrays):                 # the usual case: every support set is still arrays
+                marked = np.concatenate(id_arrays)
+                is_bp_read[marked] = True
+                e[8] = int(len(both) - np.count_nonzero(is_bp_read[both]))
+                is_bp_read[marked] = False
+            else:                                                     # somebody materialised / replaced a support set: by name
+                rbps = {t[0] for s_ in support for t in s_}
                 e[8] = sum(1 for nm in self._names_of(both) if nm not in rbps)
 
     # ---- SURVEY.md §8(f) item 2 -------------------------------------------------------------------
@@ -1236,17 +1131,31 @@ class bam_to_breakpoint_nanopore():
                           % (len(store[0]), amplicon_idx + 1))
 
             # reads without breakpoints: every alignment record of the amplicon's intervals (ibg:1296-1321)
-            concordant = set()
+            dr = self.rec
+            is_conc = np.zeros(dr.n_names, dtype=bool)
+            by_name = []                                   # name sets somebody materialised or replaced: looked up by name
             for ce in g.concordant_edges:
-                for rn in ce[9]:
-                    if rn not in self.large_indel_alignments and rn not in self.chimeric_alignments:
-                        concordant.add(rn)
-            if concordant:
-                dr = self.rec
+                ids = ce[9].name_ids() if isinstance(ce[9], ReadNameSet) else None
+                if ids is not None:
+                    is_conc[ids] = True
+                else:
+                    by_name.append(ce[9])
+            if by_name:
                 name_to_id = self._name_ids()
-                ids = np.fromiter((name_to_id[rn] for rn in concordant), dtype=np.int64, count=len(concordant))
-                is_conc = np.zeros(dr.n_names, dtype=bool)
-                is_conc[ids] = True
+                for rn in set().union(*by_name):
+                    is_conc[name_to_id[rn]] = True
+            if is_conc.any():                              # minus the reads with breakpoints (ibg:1299)
+                lia = self.large_indel_alignments
+                if lia:
+                    name_to_id = self._name_ids()
+                    is_conc[np.fromiter((name_to_id[rn] for rn in lia), dtype=np.int64, count=len(lia))] = False
+                if self._chim is not None and len(self._chim.name_id) and len(self.chimeric_alignments) == len(self._chim.name_id):
+                    is_conc[self._chim.name_id] = False
+                else:
+                    name_to_id = self._name_ids()
+                    for rn in self.chimeric_alignments:
+                        is_conc[name_to_id[rn]] = False
+            if is_conc.any():
                 for aint in self.amplicon_intervals:
                     if amplicon_idx != self.ccid2id[aint[3]] - 1:
                         continue
@@ -1355,15 +1264,6 @@ class _SegIndexView:
 
 
 PHASE_SECONDS: Dict[str, float] = {}      # wall time of every phase of the last build (same phases the reference logs)
-
-
-def _bind_thread_to_device(device):
-    """The current GPU is a per-thread setting of the HIP runtime: worker threads must select the records' device before
-    they launch kernels on its streams."""
-    import torch
-    dev = torch.device(device)
-    if dev.type == "cuda":
-        torch.cuda.set_device(dev)
 
 
 def build_graph_from_records(records, seedfile, cn_seg, output_prefix=None, min_bp_support=1.0, output_bp=False,

@@ -186,85 +186,6 @@ def point_cover(dr, points: Sequence[Tuple[int, int]], pair_cap: int = 1 << 20, 
     return [per_uniq[j] for j in inverse.reshape(-1)]
 
 
-def _bp_candidates_local(dr, T, sel, mode: int, intervals, chr_rank, cutoff: int, min_mapq: int, gap_: int, gap_mapq: int,
-                         groups=None):
-    """int32 [K, 13] candidate rows from coral_bp_candidates (runs on this process's GPU; the chimeric table is small and
-    lives with the host logic, so this step is not sharded).  Mode 2 (``groups`` = interval index per selected read)
-    additionally returns the exclusive prefix of the per-read candidate counts (int32 [n_sel + 1])."""
-    from .chimeric import ChimericTable  # noqa: F401
-    L = _lib.lib()
-    dev = dr.device
-    n_sel = T.n_reads if sel is None else len(sel)
-    if n_sel == 0 or T.n_rows == 0:
-        empty = np.zeros((0, 13), dtype=np.int32)
-        return (empty, np.zeros(n_sel + 1, dtype=np.int32)) if mode == 2 else empty
-    off, qs, qe, tid, ra, rb, strand, mapq = T.device_arrays(dev)
-    ct = _lib.coral_chimeric_t(T.n_reads, off.data_ptr(), qs.data_ptr(), qe.data_ptr(), tid.data_ptr(), ra.data_ptr(),
-                               rb.data_ptr(), strand.data_ptr(), mapq.data_ptr())
-    # one upload for all small inputs: [selection (| interval index per read) | interval tid | start | end | chromosome ranks]
-    iv = np.asarray(intervals, dtype=np.int32).reshape(-1, 3)
-    parts = [] if sel is None else [np.asarray(sel, dtype=np.int32)]
-    if mode == 2:
-        parts.append(np.asarray(groups, dtype=np.int32))
-    parts += [iv[:, 0], iv[:, 1], iv[:, 2], np.asarray(chr_rank, dtype=np.int32)]
-    packed = torch.from_numpy(np.concatenate(parts)).to(dev)
-    at = packed.data_ptr()
-    sel_ptr = None
-    if sel is not None:
-        sel_ptr = at
-        at += 4 * n_sel * (2 if mode == 2 else 1)
-    it_ptr, is_ptr, ie_ptr, cr_ptr = at, at + 4 * len(iv), at + 8 * len(iv), at + 12 * len(iv)
-    counts = torch.empty(n_sel + 2, dtype=torch.int32, device=dev)
-    cap = max(1024, 2 * n_sel)
-    while True:
-        cand = torch.empty((cap, 13), dtype=torch.int32, device=dev)
-        n_out = C.c_int32(0)
-        rc = L.coral_bp_candidates(C.byref(ct), n_sel, sel_ptr, mode, len(iv), it_ptr, is_ptr, ie_ptr, cr_ptr, len(chr_rank), cutoff,
-                                   min_mapq, gap_, gap_mapq, counts.data_ptr(), cand.data_ptr(), cap, C.byref(n_out),
-                                   dr.stream())
-        if rc == -3:                      # CORAL_ERR_CAPACITY
-            cap = int(n_out.value)
-            continue
-        if rc == -4:                      # CORAL_ERR_FORMAT: contig outside chr1..22,X,Y,M
-            raise KeyError("contig name outside chr1..22,X,Y,M")      # gn:13-18 lookup at bu:293
-        _lib.check(rc, "coral_bp_candidates")
-        rows = cand[:n_out.value].cpu().numpy()
-        if mode == 2:
-            return rows, counts[:n_sel + 1].cpu().numpy()
-        return rows
-
-
-def bp_candidates(dr, T, sel, mode: int, intervals, chr_rank, cutoff=100, min_mapq=20, gap_=100, gap_mapq=10):
-    """Breakpoint candidates (coral_amd.chimeric.Candidates) of the chimeric reads ``sel`` (None = all, dict order)."""
-    from .chimeric import Candidates
-    rows = _bp_candidates_local(dr, T, sel, mode, intervals, chr_rank, cutoff, min_mapq, gap_, gap_mapq).astype(np.int64)
-    return Candidates(**{k: rows[:, j] for j, k in enumerate(Candidates.FIELDS)})
-
-
-def bp_candidates_grouped(dr, T, reads_per_query, first_intervals, second_interval, chr_rank, cutoff=100, min_mapq=20, gap_mapq=10):
-    """Several alignment2bp queries (bu:70-96) that share their second interval, in ONE coral_bp_candidates launch (mode 2).
-
-    ``reads_per_query[g]``: reads (indices into T, iteration order) of query g; ``first_intervals[g]`` its (tid, start, end).
-    Returns one ``Candidates`` per query, rows in the reference's order."""
-    from .chimeric import Candidates
-    if not reads_per_query:
-        return []
-    sizes = [len(r) for r in reads_per_query]
-    sel = np.concatenate([np.asarray(r, dtype=np.int32) for r in reads_per_query]) if sum(sizes) else np.zeros(0, dtype=np.int32)
-    groups = np.repeat(np.arange(len(sizes), dtype=np.int32), sizes)
-    rows, prefix = _bp_candidates_local(dr, T, sel, 2, list(first_intervals) + [second_interval], chr_rank, cutoff, min_mapq, 100,
-                                        gap_mapq, groups=groups)
-    rows = rows.astype(np.int64)
-    bounds = np.concatenate([[0], np.cumsum(sizes)])
-    out = []
-    for g in range(len(sizes)):
-        a = int(prefix[bounds[g]]) if bounds[g] < len(prefix) else len(rows)
-        b = int(prefix[bounds[g + 1]]) if bounds[g + 1] < len(prefix) else len(rows)
-        part = rows[a:b]
-        out.append(Candidates(**{k: part[:, j] for j, k in enumerate(Candidates.FIELDS)}))
-    return out
-
-
 def _sa_table_local(dr):
     """coral_sa_table on this process's GPU over ALL records' SA rows (they are tiny next to the CIGARs; the table is
     consumed by the host logic, so it is built where that runs).  Returns numpy arrays
@@ -273,7 +194,7 @@ def _sa_table_local(dr):
     dev = dr.device
     d = dr.sa_device_arrays()
     n_sa = dr.n_sa
-    ws_bytes = max(1 << 20, 96 * max(n_sa, 1) + 8 * dr.n_names + (8 << 20))
+    ws_bytes = max(1 << 20, 104 * max(n_sa, 1) + 8 * dr.n_names + (8 << 20))
     out_rows = torch.empty((max(n_sa, 1), 8), dtype=torch.int32, device=dev)
     out_off = torch.empty(max(n_sa, 1) + 1, dtype=torch.int32, device=dev)
     out_name = torch.empty(max(n_sa, 1), dtype=torch.int32, device=dev)
@@ -297,15 +218,30 @@ def _sa_table_local(dr):
     if rc != 0:
         raise _lib.CoralHipError("coral_sa_table failed (%d): %s" % (rc, L.coral_sa_last_error().decode()))
     n_reads, n_rows = int(counts[0]), int(counts[1])
+    pairs = pair_table(dr, out_off, out_rows, n_reads, n_rows)
     # the rows leave the GPU column by column (transposed there): the host wants seven contiguous int64 columns, and cutting
     # them out of a row-major [n, 8] array costs more than the whole kernel
     cols = out_rows[:n_rows].t().contiguous().to(torch.int64).cpu().numpy()
     return (cols, out_off[:n_reads + 1].cpu().numpy().astype(np.int64),
             out_name[:n_reads].cpu().numpy().astype(np.int64), out_failed[:n_reads].cpu().numpy().astype(bool),
-            out_rl[:dr.n_names].cpu().numpy().astype(np.int64))
+            out_rl[:dr.n_names].cpu().numpy().astype(np.int64), pairs[:2 * n_rows].cpu().numpy())
+
+
+def pair_table(dr, off: torch.Tensor, rows: torch.Tensor, n_reads: int, n_rows: int, cutoff=100, min_mapq=20, gap_=100,
+               gap_mapq=10) -> torch.Tensor:
+    """coral_bp_pair_table (K4) on device arrays in coral_sa_table's layout (off int32[n_reads + 1], rows int32[n_rows, 8]):
+    int32 [2 * n_rows, 8] on the device, launched on the records' stream."""
+    dev = dr.device
+    assert off.dtype == torch.int32 and rows.dtype == torch.int32 and rows.is_contiguous() and off.is_contiguous()
+    assert off.numel() >= n_reads + 1 and rows.numel() >= 8 * n_rows
+    pairs = torch.empty((2 * max(n_rows, 1), 8), dtype=torch.int32, device=dev)
+    chr_rank = torch.from_numpy(dr.chr_rank).to(dev)
+    _lib.check(_lib.lib().coral_bp_pair_table(n_reads, n_rows, off.data_ptr(), rows.data_ptr(), chr_rank.data_ptr(), len(dr.chr_rank),
+                                              cutoff, min_mapq, gap_, gap_mapq, pairs.data_ptr(), dr.stream()), "coral_bp_pair_table")
+    return pairs
 
 
 def sa_table(dr):
     """(columns int64 [8, n_rows] = qs, qe, tid, ra, rb, strand, mapq, nm; row offsets per read; name id per read; failed flag
-    per read; read length per name id) — coral_sa_table over all SA rows."""
+    per read; read length per name id; pair table) — coral_sa_table + coral_bp_pair_table over all SA rows."""
     return _sa_table_local(dr)

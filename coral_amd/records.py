@@ -82,6 +82,8 @@ class DeviceRecords:
         self.h_nonacgt_rec = h(rec.nonacgt_rec).astype(np.int64)
         self.h_nonacgt_pos = h(rec.nonacgt_pos).astype(np.int32)
         self.n_names = int(rec.n_names)
+        from .global_names import chr_idx
+        self.chr_rank = np.array([chr_idx.get(c, -1) for c in self.header_chroms], dtype=np.int32)     # gn:13-18; -1 = other contig
         self._rec = rec
         self._names: Optional[List[str]] = rec.names
         self.total_ops_all = int(self.h_n_cigar.astype(np.int64).sum())

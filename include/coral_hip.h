@@ -131,34 +131,59 @@ int coral_sa_table(int32_t n_rec, const int32_t *rec_tid, const int32_t *rec_fla
 const char *coral_sa_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
- * coral_bp_candidates — breakpoint candidates from the chimeric (SA-derived) local alignments of many reads.
+ * coral_bp_pair_table — the breakpoint candidate of EVERY pair of local alignments of every chimeric read (K4).
  *
- * Replaces the per-read loops over alignment2bp_l (/root/reference/src/infer_breakpoint_graph.py:687-688 ->
- * breakpoint_utilities.py:129-186; mode 0, all amplicon intervals) and alignment2bp (infer_breakpoint_graph.py:432-434
- * -> breakpoint_utilities.py:70-96; mode 1, exactly two intervals I1, I2), including interval2bp
- * (breakpoint_utilities.py:289-295).  The chimeric table is a device SoA: rows of read r are off[r]..off[r+1], in the
- * reference's (qs, qe)-sorted order; ra/rb are rint[1]/rint[2] (ra > rb on '-' rows); strand 0 '+', 1 '-'.
- * Mode 2 batches several mode-1 queries that share their second interval (all target intervals of one step of the
- * interval search, ibg:405-434): `sel` then holds 2 * n_sel ints — the reads, then for every read the index of ITS first
- * interval — and every read is paired with the LAST of the n_int intervals; after the call counts[0..n_sel] (device) is
- * the exclusive prefix of the per-read candidate counts, i.e. where each read's (and so each query's) rows start.
- * `sel` lists the reads to process in iteration order (NULL = all reads).  Output rows are 13 int32:
- * c1, p1, o1, c2, p2, o2, read, i, j, query gap, swapped flag, mapq of the first, mapq of the second segment — in the
- * reference's order (reads as listed; per read consecutive-pair candidates, then skip-one candidates).
- * `counts` is a device workspace of n_sel + 2 int32.  *n_out (host) receives the number of candidates; when it
- * exceeds `cap` the call returns CORAL_ERR_CAPACITY and must be repeated with a larger buffer.  Synchronises `stream`.
+ * Replaces the arithmetic of alignment2bp (/root/reference/src/breakpoint_utilities.py:70-96, called per read inside the
+ * interval search, infer_breakpoint_graph.py:432-434), of alignment2bp_l (bu:129-186, infer_breakpoint_graph.py:687-688)
+ * and of interval2bp (bu:289-295): which pairs yield a candidate depends on the amplicon intervals of the moment, but the
+ * candidate itself and every interval-independent test are pure functions of two table rows, so they are computed once.
+ *   inputs  off int32[n_reads + 1], rows int32[n_rows][8] — exactly coral_sa_table's out_off / out_rows (device);
+ *           chr_rank int32[n_tid]: rank of every BAM contig in chr1..22,X,Y,M (global_names.py:13-18), -1 = other contig
+ *   output  pairs int32[2 * n_rows][8] (device, 16-byte aligned).  Slot 2 * g + 0 = pair (g, g + 1), slot 2 * g + 1 = pair
+ *           (g - 1, g + 1) around row g ("skip one low-MAPQ alignment"); a slot whose pair leaves the read has bits = 0.
+ *           Fields: c1, p1, c2, p2, query gap, bits, row a, row b with
+ *           bits: 1 valid | 2 passes the MAPQ / query-gap tests | 4 o1 is '-' | 8 o2 is '-' | 16 ends swapped by interval2bp
+ *                 | 32 strands differ | 64 |gr - grr| > max(gap_, |0.2 gr|) | 128 a contig outside chr1..22,X,Y,M (KeyError
+ *                 in the reference) | mapq(a) << 8 | mapq(b) << 16
+ * Asynchronous on `stream`.  No limit on the number of alignments per read.
  * ------------------------------------------------------------------------------------------------ */
-typedef struct coral_chimeric {
-    int32_t n_reads;
-    const int32_t *off;                                     /* [n_reads + 1] */
-    const int32_t *qs, *qe, *tid, *ra, *rb, *strand, *mapq; /* per row */
-} coral_chimeric_t;
+int coral_bp_pair_table(int32_t n_reads, int32_t n_rows, const int32_t *off, const int32_t *rows, const int32_t *chr_rank,
+                        int32_t n_tid, int32_t min_bp_match_cutoff, int32_t min_mapq, int32_t gap_, int32_t gap_mapq,
+                        int32_t *pairs, void *stream);
 
-int coral_bp_candidates(const coral_chimeric_t *ct, int32_t n_sel, const int32_t *sel, int32_t mode, int32_t n_int,
-                        const int32_t *int_tid, const int32_t *int_start, const int32_t *int_end,
-                        const int32_t *chr_rank, int32_t n_tid, int32_t min_bp_match_cutoff, int32_t min_mapq,
-                        int32_t gap_, int32_t gap_mapq, int32_t *counts, int32_t *cand /* [cap][13] */, int32_t cap,
-                        int32_t *n_out, void *stream);
+/* ------------------------------------------------------------------------------------------------
+ * coral_search_* — host side of the amplicon-interval search (no device work): one step of find_interval_i
+ * (infer_breakpoint_graph.py:362-434) in one call, alignment2bp_l over all reads (ibg:676-690) in another.
+ *
+ * coral_search_create borrows HOST arrays (they must outlive the handle): the chimeric table (off int64[n_reads + 1];
+ * per row: owning read, contig id, rint[1], rint[2], CN-segment index of both ends (-1 none, -3 contig without CN
+ * segments)), per read hash(read name) and name id, the inverted index of hash_alignment_to_seg (e_key = contig << 32 |
+ * segment, ascending; e_row = table row), the pair table (host copy of coral_bp_pair_table's output) and the CN segments
+ * of every contig in file order (seg_off int64[n_tid + 1]; start, inclusive end).
+ * coral_search_step(tid, s, e, si, ei, min_cluster_cutoff, max_seq_len): reach sets (ibg:369-384, replayed as CPython
+ * sets: size and iteration order), segments with fewer reads than the cutoff dropped, runs of neighbouring segments
+ * (ibg:392-419), and for every run alignment2bp of the united set's reads, in the set's iteration order, between the run
+ * and (tid, s, e).  coral_search_within: alignment2bp_l of every read in table order.  coral_search_between: alignment2bp
+ * of the listed reads between two intervals.  coral_search_result then gives (valid until the next call on the handle)
+ * groups int64[n_groups][4] = contig id, first segment, last segment, candidates of the run; cand int64[n_cand][13] =
+ * c1, p1, o1, c2, p2, o2, read name id, i, j, query gap, swapped, mapq a, mapq b (the 11 fields of bu:81 / bu:294-295);
+ * order_off int64[n_groups + 1] / order int32[] = the reads of every run in iteration order (table indices).
+ * CORAL_ERR_FORMAT: a candidate touches a contig outside chr1..22,X,Y,M (KeyError at bu:293 in the reference).
+ * ------------------------------------------------------------------------------------------------ */
+void *coral_search_create(int64_t n_reads, int64_t n_rows, const int64_t *off, const int64_t *row_read, const int64_t *row_tid,
+                          const int64_t *ra, const int64_t *rb, const int64_t *cni0, const int64_t *cni1,
+                          const int64_t *read_hash, const int64_t *read_name, int64_t n_ent, const int64_t *e_key,
+                          const int64_t *e_row, const int32_t *pairs, int32_t n_tid, const int64_t *seg_off,
+                          const int64_t *seg_start, const int64_t *seg_end);
+int coral_search_free(void *handle);
+const char *coral_search_error(void *handle);
+int coral_search_step(void *handle, int64_t tid, int64_t s, int64_t e, int64_t si, int64_t ei, double min_cluster_cutoff,
+                      int64_t max_seq_len);
+int coral_search_within(void *handle, int32_t n_int, const int64_t *int_tid, const int64_t *int_start, const int64_t *int_end);
+int coral_search_between(void *handle, int64_t n_sel, const int32_t *reads, int64_t t1, int64_t s1, int64_t e1, int64_t t2,
+                         int64_t s2, int64_t e2);
+int coral_search_result(void *handle, int64_t *n_groups, const int64_t **groups, int64_t *n_cand, const int64_t **cand,
+                        const int64_t **order_off, const int32_t **order);
 
 /* ------------------------------------------------------------------------------------------------
  * coral_read_counter — copy a device counter to the host (synchronises `stream`).

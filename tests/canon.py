@@ -1,13 +1,14 @@
 """Canonical JSON-able form shared by golden files and the objects under test."""
 import hashlib
 import json
+from collections.abc import Set
 
 import numpy as np
 
 
 def canon(o):
     """sets -> tagged sorted lists, dicts -> tagged ordered pair lists, tuples -> lists."""
-    if isinstance(o, (set, frozenset)):
+    if isinstance(o, (set, frozenset, Set)):           # incl. the lazily materialised sets of coral_amd.lazysets
         return {"__set__": sorted((canon(x) for x in o), key=lambda v: json.dumps(v))}
     if isinstance(o, dict):
         return {"__dict__": [[canon(k), canon(v)] for k, v in o.items()]}

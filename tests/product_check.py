@@ -134,7 +134,43 @@ def check_product_against_golden(case, golden_dir, tmp_path, device):
     return b
 
 
-# ---- oracle-backed stand-ins for the three device kernels (CPU tests of the host logic only) ----------------
+def pair_table_cpu(cols, off, chroms, chr_rank, cutoff=100, min_mapq=20, gap_=100, gap_mapq=10):
+    """coral_bp_pair_table stand-in (layout of csrc/coral_kernels.hip K4: slot 2 * g + kind, 8 ints per slot), every candidate
+    made by the ORACLE's interval2bp; the interval-independent tests restated from bu:70-96 / :129-186."""
+    from oracle import coral_oracle as O
+    n_rows = cols.shape[1]
+    pairs = np.zeros((2 * n_rows, 8), dtype=np.int32)
+    tid_of = {c: k for k, c in enumerate(chroms)}
+    qs, qe, tid, ra, rb, strand, mapq = (cols[k].tolist() for k in range(7))
+
+    def fill(slot, a, b, mid, skip):
+        gap = qs[b] - qe[a]
+        ok = mapq[a] >= min_mapq and mapq[b] >= min_mapq and ((mapq[mid] < gap_mapq) if skip else (gap + cutoff >= 0))
+        bad = chr_rank[tid[a]] < 0 or chr_rank[tid[b]] < 0
+        if bad:            # the reference raises KeyError here; the candidate content is never looked at
+            c = [chroms[tid[a]], rb[a], "+-"[strand[a]], chroms[tid[b]], ra[b], "-+"[strand[b]], None, gap, 0]
+        else:
+            c = O.interval2bp([chroms[tid[a]], ra[a], rb[a], "+-"[strand[a]]], [chroms[tid[b]], ra[b], rb[b], "+-"[strand[b]]],
+                              ("r", 0, 1), gap)
+        grr = (ra[b] - rb[a]) if strand[b] == 0 else (rb[a] - ra[b])
+        far = abs(gap - grr) > max(gap_, abs(gap * 0.2))
+        o1, o2 = "+-".index(c[2]), "+-".index(c[5])
+        bits = 1 | (2 if ok else 0) | (o1 << 2) | (o2 << 3) | (16 if c[8] else 0) | (32 if strand[a] != strand[b] else 0) | \
+            (64 if far else 0) | (128 if bad else 0) | ((mapq[a] & 255) << 8) | ((mapq[b] & 255) << 16)
+        pairs[slot] = [tid_of[c[0]], c[1], tid_of[c[3]], c[4], gap, bits, a, b]
+
+    for r in range(len(off) - 1):
+        base, n = int(off[r]), int(off[r + 1] - off[r])
+        for k in range(n):
+            g = base + k
+            if k + 1 < n:
+                fill(2 * g, g, g + 1, g, False)
+            if 1 <= k and k + 1 < n:
+                fill(2 * g + 1, g - 1, g + 1, g, True)
+    return pairs
+
+
+# ---- oracle-backed stand-ins for the device kernels (CPU tests of the host logic only) ----------------
 def install_cpu_kernel_fakes(monkeypatch):
     from coral_amd import kernels
     from oracle.hostrecords import HostRecords
@@ -181,32 +217,6 @@ def install_cpu_kernel_fakes(monkeypatch):
             keys += [(j << 32) | (int(i) - dr.lo) for i in h.region(h.chroms[t], p, p + 1) if dr.lo <= i < dr.hi]
         return torch.tensor(keys, dtype=torch.int64)
 
-    def bp_candidates_local(dr, T, sel, mode, intervals, chr_rank, cutoff, min_mapq, gap_, gap_mapq, groups=None):
-        """coral_bp_candidates stand-in: the oracle's alignment2bp / alignment2bp_l, read by read (mode 2 = one alignment2bp
-        query per selected read's interval index against the last interval; also returns the per-read row prefix)."""
-        from oracle import coral_oracle as O
-        chroms = dr.header_chroms
-        ori = {"+": 0, "-": 1}
-        tid_of = {c: k for k, c in enumerate(chroms)}
-        rows, prefix = [], [0]
-        ivs = [[chroms[t], s, e] for t, s, e in intervals]
-        for k_sel, r in enumerate(range(T.n_reads) if sel is None else sel):
-            a, b = int(T.off[r]), int(T.off[r + 1])
-            ca = ([[int(T.qs[k]), int(T.qe[k])] for k in range(a, b)],
-                  [[chroms[T.tid[k]], int(T.ra[k]), int(T.rb[k]), "+-"[T.strand[k]]] for k in range(a, b)],
-                  [int(T.mapq[k]) for k in range(a, b)])
-            if mode == 1:
-                out = O.alignment2bp(int(r), ca, cutoff, min_mapq, ivs[0], ivs[1], gap_mapq)
-            elif mode == 2:
-                out = O.alignment2bp(int(r), ca, cutoff, min_mapq, ivs[int(groups[k_sel])], ivs[-1], gap_mapq)
-            else:
-                out = O.alignment2bp_l(int(r), ca, cutoff, min_mapq, gap_, ivs, gap_mapq)
-            for c in out:
-                rows.append([tid_of[c[0]], c[1], ori[c[2]], tid_of[c[3]], c[4], ori[c[5]], c[6][0], c[6][1], c[6][2], c[7], c[8], c[9], c[10]])
-            prefix.append(len(rows))
-        rows = np.array(rows, dtype=np.int32).reshape(-1, 13)
-        return (rows, np.array(prefix, dtype=np.int32)) if mode == 2 else rows
-
     def sa_table_local(dr):
         """coral_sa_table stand-in: the oracle's fetch() (string SA entries, per-read Python lists) turned into arrays."""
         from oracle import coral_oracle as O
@@ -229,10 +239,9 @@ def install_cpu_kernel_fakes(monkeypatch):
             rl[name_id_of[rn]] = v
         cols = np.ascontiguousarray(np.array(rows, dtype=np.int64).reshape(-1, 8).T)          # [8, n_rows], as the product's wrapper
         return (cols, np.array(off, dtype=np.int64), np.array(names, dtype=np.int64),
-                np.array(failed, dtype=bool), rl)
+                np.array(failed, dtype=bool), rl, pair_table_cpu(cols, off, h.chroms, dr.chr_rank))
 
     monkeypatch.setattr(kernels, "_sa_table_local", sa_table_local)
-    monkeypatch.setattr(kernels, "_bp_candidates_local", bp_candidates_local)
     monkeypatch.setattr(kernels, "_scan_local", scan_local)
     monkeypatch.setattr(kernels, "_coverage_local", coverage_local)
     monkeypatch.setattr(kernels, "_points_local", points_local)

@@ -69,3 +69,27 @@ def test_strided_columns_and_empty():
     c = Candidates(**{k: rows[:, j] for j, k in enumerate(Candidates.FIELDS)})   # column views: stride 13
     sizes, calls = call_breakpoints(c, 3.0, 2000, 100, 3.0, True)
     assert sizes == [40] and len(calls) == 1 and calls[0][1:3] == (5000, 90000) and len(calls[0][3]) == 40
+
+
+def test_contig_ids_beyond_64_do_not_collide():
+    """BAM headers may list thousands of contigs (decoys, alts) before the chromosome of interest: candidates whose contig
+    ids differ by multiples of 64 must stay in separate groups (bu:257-262 groups by the chromosome NAMES)."""
+    rng = np.random.default_rng(5)
+    n = 240
+    tids = np.array([6, 70, 134, 200, 3000, 3064])                 # 70 = 6 + 64, 134 = 6 + 128, 3064 = 3000 + 64
+    kw = dict(c1=rng.choice(tids, n), c2=rng.choice(tids, n), o1=rng.integers(0, 2, n), o2=rng.integers(0, 2, n),
+              p1=50_000 + rng.integers(-40, 41, n), p2=900_000 + rng.integers(-40, 41, n),
+              read=np.arange(n), i=np.zeros(n, dtype=np.int64), j=np.ones(n, dtype=np.int64), gap=np.zeros(n, dtype=np.int64),
+              swapped=np.zeros(n, dtype=np.int64), mqa=np.full(n, 60), mqb=np.full(n, 60))
+    c = Candidates(**kw)
+    groups = {}
+    for k in range(n):                                               # the reference's grouping, literally
+        groups.setdefault((int(c.c1[k]), int(c.c2[k]), int(c.o1[k]), int(c.o2[k])), []).append(k)
+    expected = [g for g in groups.values()]                          # every group is within 2000 bp: one cluster each
+    got = [cl.tolist() for cl in cluster_bp_list(c, 1.0, 2000)]
+    assert got == expected
+    sizes, calls = call_breakpoints(c, 1.0, 2000, 100, 3.0, True)
+    assert sizes == [len(g) for g in expected]
+    for (head, p1, p2, sup, st) in calls:
+        key = (int(c.c1[head]), int(c.c2[head]), int(c.o1[head]), int(c.o2[head]))
+        assert all((int(c.c1[k]), int(c.c2[k]), int(c.o1[k]), int(c.o2[k])) == key for k in sup.tolist())

@@ -173,7 +173,7 @@ def _random_layout(seed):
 
 @pytest.mark.parametrize("seed", range(8))
 def test_gpu_matches_oracle_random_layouts(seed, tmp_path):
-    """Product (HIP kernels, native host pieces, look-ahead threads forced on) vs the CPU oracle on random layouts."""
+    """Product (HIP kernels, native host pieces) vs the CPU oracle on random layouts."""
     from coral_amd import infer_breakpoint_graph as ibg
     from coral_amd.breakpoint_graph import graph_text
     from coral_amd.records import DeviceRecords
@@ -184,11 +184,7 @@ def test_gpu_matches_oracle_random_layouts(seed, tmp_path):
     rec = synth.generate(cfg, "cpu")
     cn = str(tmp_path / "cn.bed"); seeds = str(tmp_path / "seeds.bed")
     synth.write_cn_bed(cfg, cn); synth.write_seed_bed(cfg, seeds)
-    os.environ["CORAL_AHEAD_MIN_READS"] = "0"
-    try:
-        b = ibg.build_graph_from_records(DeviceRecords(rec, "cuda:0"), seeds, cn, str(tmp_path / "gpu"))
-    finally:
-        del os.environ["CORAL_AHEAD_MIN_READS"]
+    b = ibg.build_graph_from_records(DeviceRecords(rec, "cuda:0"), seeds, cn, str(tmp_path / "gpu"))
     ob, ofiles = O.reconstruct_graph(HostRecords(rec), seeds, cn)
     assert len(b.lr_graph) == len(ob.lr_graph) and b.normal_cov == ob.normal_cov
     assert sorted(map(str, b.amplicon_intervals)) == sorted(map(str, ob.amplicon_intervals))

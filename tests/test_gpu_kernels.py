@@ -216,47 +216,90 @@ def _table_from_cas(cas, chroms):
     return T
 
 
-def test_bp_candidates_against_reference_vectors(golden_dir):
-    """coral_bp_candidates vs the known-answer vectors of the REFERENCE's alignment2bp / alignment2bp_l
-    (tests/golden/unit_vectors.json), one launch per vector and one batched launch for mode 0."""
+def _search_over(T, pairs, n_tid):
+    """PairSearch over a hand-made table: only the pair filter is exercised (no CN segments, empty inverted index)."""
+    from coral_amd.chimeric import PairSearch
+    T.cni0 = np.full(T.n_rows, -1, dtype=np.int64)
+    T.cni1 = np.full(T.n_rows, -1, dtype=np.int64)
+    T.pairs = pairs
+    z = np.zeros(0, dtype=np.int64)
+    return PairSearch(T, np.zeros(T.n_reads, dtype=np.int64), z, z, np.zeros(n_tid + 1, dtype=np.int64), z, z)
+
+
+def _gpu_pairs(dr, T):
+    import torch
+    from coral_amd import kernels
+    rows = np.stack([T.qs, T.qe, T.tid, T.ra, T.rb, T.strand, T.mapq, np.zeros_like(T.qs)], axis=1).astype(np.int32)
+    out = kernels.pair_table(dr, torch.from_numpy(T.off.astype(np.int32)).to(dr.device),
+                             torch.from_numpy(np.ascontiguousarray(rows)).to(dr.device), T.n_reads, T.n_rows)
+    return out[:2 * T.n_rows].cpu().numpy()
+
+
+def candidates_as_lists(cands, chroms, name_of):
+    return [[chroms[cands.c1[k]], int(cands.p1[k]), "+-"[cands.o1[k]], chroms[cands.c2[k]], int(cands.p2[k]), "+-"[cands.o2[k]],
+             (name_of(int(cands.read[k])), int(cands.i[k]), int(cands.j[k])), int(cands.gap[k]), int(cands.swapped[k]),
+             int(cands.mqa[k]), int(cands.mqb[k])] for k in range(len(cands))]
+
+
+def test_bp_pair_table_against_reference_vectors(golden_dir):
+    """coral_bp_pair_table (K4, GPU) + the native pair filter vs the known-answer vectors of the REFERENCE's alignment2bp /
+    alignment2bp_l (tests/golden/unit_vectors.json): 240 single-read queries and one all-reads query."""
     import json, os
-    from coral_amd import kernels, synth
     from coral_amd.records import DeviceRecords
-    from coral_amd.global_names import chr_idx
     from tests.canon import uncanon_unit
     with open(os.path.join(golden_dir, "unit_vectors.json")) as fp:
         vec = json.load(fp)
     chroms = synth.CHROMS
     dr = DeviceRecords(synth.records_from_alignments([]), "cuda:0")
-    chr_rank = np.array([chr_idx[c] for c in chroms], dtype=np.int64)
     tid_of = {c: k for k, c in enumerate(chroms)}
-
-    def as_lists(cands, name_of):
-        out = []
-        for k in range(len(cands)):
-            out.append([chroms[cands.c1[k]], int(cands.p1[k]), "+-"[cands.o1[k]], chroms[cands.c2[k]], int(cands.p2[k]), "+-"[cands.o2[k]],
-                        (name_of(int(cands.read[k])), int(cands.i[k]), int(cands.j[k])), int(cands.gap[k]), int(cands.swapped[k]),
-                        int(cands.mqa[k]), int(cands.mqb[k])])
-        return out
+    cas = [uncanon_unit(v["ca"]) for v in vec["alignment2bp"]]
+    T = _table_from_cas(cas, chroms)
+    S = _search_over(T, _gpu_pairs(dr, T), len(chroms))
     n_pos = 0
     for k, v in enumerate(vec["alignment2bp"]):
-        ca = uncanon_unit(v["ca"])
-        T = _table_from_cas([ca], chroms)
-        iv = [(tid_of[v["i1"][0]], v["i1"][1], v["i1"][2]), (tid_of[v["i2"][0]], v["i2"][1], v["i2"][2])]
-        got = as_lists(kernels.bp_candidates(dr, T, np.array([0]), 1, iv, chr_rank, 100, 20, 100, 10), lambda r: "rd%d" % k)
+        i1, i2 = [(tid_of[i[0]], i[1], i[2]) for i in (v["i1"], v["i2"])]
+        got = candidates_as_lists(S.between([k], i1, i2), chroms, lambda r: "rd%d" % r)
         assert got == uncanon_unit(v["out"]), k
         n_pos += len(got)
     assert n_pos > 30
     cas = [uncanon_unit(v["ca"]) for v in vec["alignment2bp_l"]]
     ivs = [(tid_of[i[0]], i[1], i[2]) for i in vec["alignment2bp_l"][0]["intervals"]]
     T = _table_from_cas(cas, chroms)
-    got = as_lists(kernels.bp_candidates(dr, T, None, 0, ivs, chr_rank, 100, 20, 100, 10), lambda r: "rd%d" % r)
+    S = _search_over(T, _gpu_pairs(dr, T), len(chroms))
+    got = candidates_as_lists(S.within(ivs), chroms, lambda r: "rd%d" % r)
     exp = [c for v in vec["alignment2bp_l"] for c in uncanon_unit(v["out"])]
     assert got == exp and len(exp) > 30
-    # a subset in a permuted order keeps that order
-    sel = np.array([7, 3, 200, 11, 0], dtype=np.int64)
-    got = as_lists(kernels.bp_candidates(dr, T, sel, 0, ivs, chr_rank, 100, 20, 100, 10), lambda r: "rd%d" % r)
-    assert got == [c for s in sel for c in uncanon_unit(vec["alignment2bp_l"][int(s)]["out"])]
+
+
+def test_bp_pair_table_equals_cpu_stand_in():
+    """The GPU pair table equals, bit for bit, the oracle-made table the CPU host-logic tests run on (tests/product_check.py),
+    on real chimeric tables incl. reads with many alignments and low-MAPQ middles."""
+    from coral_amd.chimeric import build_chimeric_table
+    from coral_amd.records import DeviceRecords
+    from tests.product_check import pair_table_cpu
+    for name in ("tiny_edge", "ultra", "small"):
+        cfg, rec = synth.dataset(name, "cpu")
+        dr = DeviceRecords(rec, "cuda:0")
+        T = build_chimeric_table(dr)
+        cols = np.stack([T.qs, T.qe, T.tid, T.ra, T.rb, T.strand, T.mapq])
+        want = pair_table_cpu(cols, T.off, dr.header_chroms, dr.chr_rank)
+        assert T.pairs.shape == want.shape and np.array_equal(T.pairs, want), name
+        assert (T.pairs[:, 5] & 2).sum() > 50
+
+
+def test_reads_with_more_than_64_alignments():
+    """No per-read limit: a read with 90 distinct SA entries goes through coral_sa_table and the pair table (the reference has
+    no limit either)."""
+    from coral_amd.chimeric import build_chimeric_table
+    from coral_amd.records import DeviceRecords
+    M, S = 0, 4
+    n = 90
+    sa = [(0, 1000 + 700 * k, k % 2, 100 * k if k else 0, 100, 0, 100 * (n - k), 60, 1) for k in range(1, n + 1)]
+    recs = [dict(tid=0, pos=10, cigar=[(M, 100), (S, 100 * n)], name="long", sa=sa), dict(tid=0, pos=20, cigar=[(M, 50)], name="y")]
+    T = build_chimeric_table(DeviceRecords(synth.records_from_alignments(recs), "cuda:0"))
+    assert T.n_reads == 1 and T.n_rows == n
+    assert (np.diff(T.qs) >= 0).all()
+    assert T.pairs.shape == (2 * n, 8) and (T.pairs[:, 5] & 1).sum() == (n - 1) + (n - 2)
 
 
 @pytest.mark.parametrize("name", ["tiny", "tiny_edge", "small", "ultra"])
@@ -307,30 +350,3 @@ def test_sa_table_error_semantics():
         dict(tid=0, pos=20, cigar=[(M, 50)], name="y")])
     with pytest.raises(ZeroDivisionError):
         build_chimeric_table(DeviceRecords(zero, "cuda:0"))
-
-
-def test_bp_candidates_grouped_equals_single_queries():
-    """Mode 2 of coral_bp_candidates (all target runs of one step of the interval search in ONE launch) returns, query by
-    query, exactly the rows of separate mode-1 launches — including empty queries and reads listed in several queries."""
-    from coral_amd import kernels
-    from coral_amd.chimeric import build_chimeric_table, Candidates
-    from coral_amd.records import DeviceRecords
-    from coral_amd.global_names import chr_idx
-    cfg, rec = synth.dataset("ultra", "cpu")
-    dr = DeviceRecords(rec, "cuda:0")
-    T = build_chimeric_table(dr)
-    chr_rank = np.array([chr_idx.get(c, -1) for c in dr.header_chroms], dtype=np.int64)
-    rng = np.random.default_rng(3)
-    segs = [(sg.tid, sg.start, sg.end) for circle in cfg.circles for sg in circle]
-    here = segs[0]
-    queries, targets = [], []
-    for g in range(9):
-        n = int(rng.choice([0, 1, 40, 250]))
-        queries.append(rng.integers(0, T.n_reads, n))
-        targets.append(segs[1 + g % (len(segs) - 1)])
-    got = kernels.bp_candidates_grouped(dr, T, queries, targets, here, chr_rank)
-    assert len(got) == len(queries) and sum(len(c) for c in got) > 20
-    for reads, tgt, c in zip(queries, targets, got):
-        want = kernels.bp_candidates(dr, T, reads, 1, [tgt, here], chr_rank)
-        for f in Candidates.FIELDS:
-            assert np.array_equal(getattr(c, f), getattr(want, f)), f
