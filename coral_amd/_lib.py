@@ -70,6 +70,8 @@ def lib():
                                  C.POINTER(C.c_int32), P]
     L.coral_sa_table.restype = C.c_int
     L.coral_sa_last_error.restype = C.c_char_p
+    L.coral_hash_rows.argtypes = [C.c_int32, P, C.c_int32, P, P, P, P, P, C.c_int32, P, C.c_int64, P, P, P, P, C.POINTER(C.c_int32), P]
+    L.coral_hash_rows.restype = C.c_int
     L.coral_pyset_batch_create.argtypes = [C.c_int64, P, P, P, C.c_int32, P]
     L.coral_pyset_batch_create.restype = C.c_void_p
     L.coral_pyset_union_order.argtypes = [C.c_void_p, C.c_int32, P, P, C.POINTER(C.c_int32)]

@@ -35,6 +35,7 @@ class ChimericTable:
         self.nm = np.zeros(0, np.float64)
         self.read_length = np.zeros(0, np.int64)      # per name id, -1 = no primary seen
         self.pairs = np.zeros((0, 8), np.int32)       # coral_bp_pair_table: two slots per row (see csrc/coral_kernels.hip, K4)
+        self.dev_rows = None                          # coral_sa_table's rows as they stay in HBM (int32 [n_rows, 8])
         self.n_mapq60_plain = 0
 
     @property
@@ -60,7 +61,7 @@ def build_chimeric_table(dr) -> ChimericTable:
         raise ZeroDivisionError("division by zero")
     _lib.check(rc, "coral_nm_stats")
     T.n_mapq60_plain, T.nm_sum, T.nm_sum_sq = int(cnt.value), float(s0.value), float(s1.value)
-    cols, off, name_id, failed, rl, T.pairs = kernels.sa_table(dr)
+    cols, off, name_id, failed, rl, T.pairs, T.dev_rows = kernels.sa_table(dr)
     T.read_length = rl
     T.name_id, T.failed, T.off = name_id, failed, off
     T.qs, T.qe, T.tid, T.ra, T.rb, T.strand, T.mapq = (cols[k] for k in range(7))

@@ -288,3 +288,114 @@ extern "C" int coral_sa_table(int32_t n_rec, const int32_t *rec_tid, const int32
     counts[1] = n_rows;
     return CORAL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// coral_hash_rows — hash_alignment_to_seg (/root/reference/src/infer_breakpoint_graph.py:181-210) on the SA table's
+// device rows: the CN segment holding each end of every local alignment (the reference's two IntervalTree point queries
+// per alignment) and the inverted index (contig, segment) -> alignments in the reference's append order.
+//   k_hash_rows: one thread per table row, two binary searches over the (contig, start)-sorted disjoint segment table;
+//   the up to two (segment, row) entries of a row get the key contig << 32 | segment, and ONE stable radix sort of the
+//   keys (values = 2 * row + end, i.e. already in append order) yields every per-segment list in order.
+// ---------------------------------------------------------------------------------------------
+#define HASH_INVALID 0x7fffffffffffffffLL
+
+__device__ __forceinline__ int seg_lookup(const int32_t *__restrict__ seg_tid, const int32_t *__restrict__ seg_start,
+                                          const int32_t *__restrict__ seg_end, const int32_t *__restrict__ seg_idx, int n_seg,
+                                          int t, int p) {
+    int lo = 0, hi = n_seg;                 // last segment with (tid, start) <= (t, p)
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int mt = seg_tid[mid];
+        if (mt < t || (mt == t && seg_start[mid] <= p)) lo = mid + 1; else hi = mid;
+    }
+    const int k = lo - 1;
+    return (k >= 0 && seg_tid[k] == t && p < seg_end[k]) ? seg_idx[k] : -1;
+}
+
+__global__ __launch_bounds__(256) void k_hash_rows(int n_rows, const int32_t *__restrict__ rows, int n_seg,
+                                                   const int32_t *__restrict__ seg_tid, const int32_t *__restrict__ seg_start,
+                                                   const int32_t *__restrict__ seg_end, const int32_t *__restrict__ seg_idx,
+                                                   const int32_t *__restrict__ tid_has_segs, int n_tid,
+                                                   int32_t *__restrict__ cni0, int32_t *__restrict__ cni1,
+                                                   long long *__restrict__ keys, int32_t *__restrict__ vals,
+                                                   uint32_t *__restrict__ n_valid) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    int nv = 0;
+    if (r < n_rows) {
+        const int32_t *f = rows + 8ll * r;
+        const int t = f[2], a = f[3], b = f[4];
+        int c0 = -3, c1 = -3;                                  // -3: the contig has no CN segments (ibg:210: set([-1]))
+        if (t >= 0 && t < n_tid && tid_has_segs[t]) {
+            c0 = seg_lookup(seg_tid, seg_start, seg_end, seg_idx, n_seg, t, a < b ? a : b);
+            c1 = seg_lookup(seg_tid, seg_start, seg_end, seg_idx, n_seg, t, a < b ? b : a);
+        }
+        cni0[r] = c0;
+        cni1[r] = c1;
+        const bool v0 = c0 >= 0, v1 = c1 >= 0 && c1 != c0;
+        keys[2ll * r] = v0 ? (((long long)t << 32) | (long long)c0) : HASH_INVALID;
+        keys[2ll * r + 1] = v1 ? (((long long)t << 32) | (long long)c1) : HASH_INVALID;
+        vals[2ll * r] = 2 * r;
+        vals[2ll * r + 1] = 2 * r + 1;
+        nv = (v0 ? 1 : 0) + (v1 ? 1 : 0);
+    }
+    // one atomic per wave
+    for (int d = 32; d > 0; d >>= 1) nv += __shfl_xor(nv, d);
+    if ((threadIdx.x & 63) == 0 && nv) atomicAdd(n_valid, (uint32_t)nv);
+}
+
+__global__ void k_hash_finish(int n, const int32_t *__restrict__ vals_sorted, int32_t *__restrict__ e_row) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) e_row[i] = vals_sorted[i] >> 1;
+}
+
+extern "C" int coral_hash_rows(int32_t n_rows, const int32_t *rows, int32_t n_seg, const int32_t *seg_tid,
+                               const int32_t *seg_start, const int32_t *seg_end, const int32_t *seg_idx,
+                               const int32_t *tid_has_segs, int32_t n_tid, void *workspace, int64_t workspace_bytes,
+                               int32_t *cni0, int32_t *cni1, int64_t *e_key, int32_t *e_row, int32_t *n_ent, void *stream) {
+    if (!n_ent) return sa_err(CORAL_ERR_ARG, "hash_rows: n_ent is null");
+    *n_ent = 0;
+    if (n_rows < 0 || n_seg < 0 || n_tid < 0) return sa_err(CORAL_ERR_ARG, "hash_rows: negative size");
+    if (n_rows == 0) return CORAL_OK;
+    if (!rows || !tid_has_segs || !cni0 || !cni1 || !e_key || !e_row || (n_seg > 0 && (!seg_tid || !seg_start || !seg_end || !seg_idx)))
+        return sa_err(CORAL_ERR_ARG, "hash_rows: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t ne = 2 * (size_t)n_rows;
+    size_t cub_bytes = 0;
+    {
+        long long *k64 = nullptr;
+        int32_t *v32 = nullptr;
+        hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, k64, k64, v32, v32, (int)ne, 0, 63, s);
+    }
+    size_t need;
+    {
+        char *p = nullptr;
+        carve<char>(p, cub_bytes);
+        carve<long long>(p, ne);
+        carve<int32_t>(p, ne);
+        carve<int32_t>(p, ne);
+        carve<uint32_t>(p, 4);
+        need = (size_t)p;
+    }
+    if (!workspace || (size_t)workspace_bytes < need) {
+        *n_ent = (int32_t)(need >> 20) + 1;               // MiB needed
+        return sa_err(CORAL_ERR_CAPACITY, "hash_rows: workspace too small");
+    }
+    char *p = (char *)workspace;
+    void *cub_tmp = carve<char>(p, cub_bytes);
+    long long *keys = carve<long long>(p, ne);
+    int32_t *vals = carve<int32_t>(p, ne), *vals_s = carve<int32_t>(p, ne);
+    uint32_t *counter = carve<uint32_t>(p, 4);
+    (void)hipMemsetAsync(counter, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL(k_hash_rows, dim3((n_rows + 255) / 256), dim3(256), 0, s, (int)n_rows, rows, (int)n_seg, seg_tid, seg_start,
+                       seg_end, seg_idx, tid_has_segs, (int)n_tid, cni0, cni1, keys, vals, counter);
+    size_t tb = cub_bytes;
+    // sorted keys go straight to e_key; the invalid entries (key 2^63 - 1) sort behind every valid one
+    hipcub::DeviceRadixSort::SortPairs(cub_tmp, tb, keys, reinterpret_cast<long long *>(e_key), vals, vals_s, (int)ne, 0, 63, s);
+    hipLaunchKernelGGL(k_hash_finish, dim3((int)((ne + 255) / 256)), dim3(256), 0, s, (int)ne, vals_s, e_row);
+    uint32_t h = 0;
+    hipError_t e = hipMemcpyAsync(&h, counter, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return sa_err(CORAL_ERR_HIP, hipGetErrorString(e));
+    *n_ent = (int32_t)h;
+    return CORAL_OK;
+}

@@ -361,30 +361,29 @@ class bam_to_breakpoint_nanopore():
         """CN-segment indices of both ends of every SA segment + the inverted index (ibg:181-210)."""
         T = self._chim
         chroms = self.rec.header_chroms
-        lo = np.minimum(T.ra, T.rb)
-        hi = np.maximum(T.ra, T.rb)
-        T.cni0[:] = -3                     # -3: chromosome absent from the CN file -> set([-1]) (ibg:210)
-        T.cni1[:] = -3
+        n_tid = len(chroms)
         if all(v[4] for v in self.cns_tree.values()):
-            # every chromosome's segments are disjoint (the usual case): ONE binary search over all segments, keyed (tid, start)
+            # every chromosome's segments are disjoint (the usual case): coral_hash_rows on the SA table's device rows — two
+            # binary searches per alignment and one stable radix sort for the inverted index
             parts = [(self._tid_of[c], v) for c, v in self.cns_tree.items() if c in self._tid_of]
-            has_tree = np.zeros(len(chroms) + 1, dtype=bool)
+            has_tree = np.zeros(n_tid, dtype=np.int32)
+            seg = np.zeros((4, 0), dtype=np.int32)
             if parts:
                 g_tid = np.concatenate([np.full(len(v[3]), t, dtype=np.int64) for t, v in parts])
-                g_st = np.concatenate([v[0][v[3]] for _, v in parts]).astype(np.int64)
-                g_en = np.concatenate([v[1][v[3]] for _, v in parts]).astype(np.int64)
-                g_ix = np.concatenate([v[2][v[3]] for _, v in parts]).astype(np.int64)
-                o = np.argsort(g_tid * (1 << 32) + g_st, kind="stable")
-                g_tid, g_st, g_en, g_ix = g_tid[o], g_st[o], g_en[o], g_ix[o]
-                g_key = g_tid * (1 << 32) + g_st
-                has_tree[[t for t, _ in parts]] = True
-                known_row = has_tree[T.tid]
-                for dst, p in ((T.cni0, lo), (T.cni1, hi)):
-                    k = np.searchsorted(g_key, T.tid * (1 << 32) + p, side="right") - 1
-                    kk = np.clip(k, 0, len(g_key) - 1)
-                    ok = (k >= 0) & (g_tid[kk] == T.tid) & (p < g_en[kk])
-                    dst[:] = np.where(known_row, np.where(ok, g_ix[kk], -1), -3)
+                g_st = np.concatenate([v[0][v[3]] for _, v in parts])
+                g_en = np.concatenate([v[1][v[3]] for _, v in parts])
+                g_ix = np.concatenate([v[2][v[3]] for _, v in parts])
+                o = np.lexsort((g_st, g_tid))
+                seg = np.stack([g_tid[o], g_st[o], g_en[o], g_ix[o]]).astype(np.int32)
+                has_tree[[t for t, _ in parts]] = 1
+            c0, c1, self._e_key, self._e_row = kernels.hash_rows(self.rec, T, seg, has_tree)
+            T.cni0[:] = c0
+            T.cni1[:] = c1
         else:
+            lo = np.minimum(T.ra, T.rb)
+            hi = np.maximum(T.ra, T.rb)
+            T.cni0[:] = -3                     # -3: chromosome absent from the CN file -> set([-1]) (ibg:210)
+            T.cni1[:] = -3
             for t in np.unique(T.tid):
                 c = chroms[t]
                 if c not in self.cns_tree:
@@ -392,30 +391,20 @@ class bam_to_breakpoint_nanopore():
                 m = T.tid == t
                 T.cni0[m] = self._pos2cni_many(c, lo[m])
                 T.cni1[m] = self._pos2cni_many(c, hi[m])
+            # inverted index (chr, cni) -> reads, in the reference's append order (read, then segment): up to two entries per
+            # row, generated in row order, then one STABLE sort by (chromosome, segment)
+            rows = np.nonzero(T.cni0 != -3)[0]
+            a, b = T.cni0[rows], T.cni1[rows]
+            ent_row = np.repeat(rows, 2)
+            ent_cni = np.stack([a, b], axis=1).ravel()
+            valid = np.stack([a >= 0, (b >= 0) & (b != a)], axis=1).ravel()
+            ent_row, ent_cni = ent_row[valid], ent_cni[valid]
+            key = T.tid[ent_row] * (1 << 32) + ent_cni
+            o = np.argsort(key, kind="stable")
+            self._e_row, self._e_key = ent_row[o], key[o]
         self._hashed = True
         self.chimeric_alignments.invalidate()
-        # inverted index (chr, cni) -> reads, in the reference's append order (read, then segment)
-        known = T.cni0 != -3
-        rows = np.nonzero(known)[0]
-        a, b = T.cni0[rows], T.cni1[rows]
-        # up to two entries per row, generated in row order (= the reference's append order inside every list) ...
-        ent_row = np.repeat(rows, 2)
-        ent_cni = np.stack([a, b], axis=1).ravel()
-        valid = np.stack([a >= 0, (b >= 0) & (b != a)], axis=1).ravel()
-        ent_row, ent_cni = ent_row[valid], ent_cni[valid]
-        ent_tid = T.tid[ent_row]
-        # ... then one STABLE sort by (chromosome, segment): a 16-bit key (segment ordinal over all chromosomes) sorts in O(n)
-        n_tid = len(chroms)
-        seg_count = np.zeros(n_tid + 1, dtype=np.int64)
-        for t, c in enumerate(chroms):
-            seg_count[t + 1] = len(self.cns_intervals_by_chr.get(c, ()))
-        seg_base = np.cumsum(seg_count)
-        if seg_base[-1] < 32768:
-            o = np.argsort((seg_base[ent_tid] + ent_cni).astype(np.int16), kind="stable")
-        else:
-            o = np.lexsort((ent_row, ent_cni, ent_tid))
-        self._e_row, self._e_cni, self._e_tid = ent_row[o], ent_cni[o], ent_tid[o]
-        self._e_key = self._e_tid * (1 << 32) + self._e_cni
+        rows = np.nonzero(T.cni0 != -3)[0]
         kt = T.tid[rows]
         present = np.nonzero(np.bincount(kt, minlength=n_tid))[0] if len(kt) else np.zeros(0, dtype=np.int64)
         first_at = {int(t): int(np.argmax(kt == t)) for t in present}
@@ -1254,8 +1243,8 @@ class _SegIndexView:
         # chromosome key order: first appearance along (read, segment) order
         for t in o._seg_tids:
             out[chroms[t]] = {}
-        for row, cni in zip(o._e_row, o._e_cni):
-            out[chroms[T.tid[row]]].setdefault(int(cni), []).append(o._chim_names[T.read[row]])
+        for row, key in zip(o._e_row.tolist(), o._e_key.tolist()):
+            out[chroms[T.tid[row]]].setdefault(key & 0xFFFFFFFF, []).append(o._chim_names[T.read[row]])
         return out
 
     def __contains__(self, c):

@@ -224,7 +224,7 @@ def _sa_table_local(dr):
     cols = out_rows[:n_rows].t().contiguous().to(torch.int64).cpu().numpy()
     return (cols, out_off[:n_reads + 1].cpu().numpy().astype(np.int64),
             out_name[:n_reads].cpu().numpy().astype(np.int64), out_failed[:n_reads].cpu().numpy().astype(bool),
-            out_rl[:dr.n_names].cpu().numpy().astype(np.int64), pairs[:2 * n_rows].cpu().numpy())
+            out_rl[:dr.n_names].cpu().numpy().astype(np.int64), pairs[:2 * n_rows].cpu().numpy(), out_rows[:n_rows])
 
 
 def pair_table(dr, off: torch.Tensor, rows: torch.Tensor, n_reads: int, n_rows: int, cutoff=100, min_mapq=20, gap_=100,
@@ -243,5 +243,42 @@ def pair_table(dr, off: torch.Tensor, rows: torch.Tensor, n_reads: int, n_rows: 
 
 def sa_table(dr):
     """(columns int64 [8, n_rows] = qs, qe, tid, ra, rb, strand, mapq, nm; row offsets per read; name id per read; failed flag
-    per read; read length per name id; pair table) — coral_sa_table + coral_bp_pair_table over all SA rows."""
+    per read; read length per name id; pair table; the rows as they stay on the device) — coral_sa_table + coral_bp_pair_table
+    over all SA rows."""
     return _sa_table_local(dr)
+
+
+def _hash_rows_local(dr, T, seg: np.ndarray, tid_has_segs: np.ndarray):
+    """coral_hash_rows on the device rows of ``T``; ``seg`` int32 [4, n_seg] = contig id, start, end (exclusive), index within
+    the contig — sorted by (contig, start), disjoint.  Returns (cni0, cni1, e_key, e_row) as int64 numpy arrays."""
+    L = _lib.lib()
+    dev = dr.device
+    n_rows = T.n_rows
+    rows = T.dev_rows
+    assert rows is not None and rows.shape == (n_rows, 8) and rows.dtype == torch.int32 and rows.is_contiguous()
+    sg = torch.from_numpy(np.ascontiguousarray(seg, dtype=np.int32)).to(dev)
+    has = torch.from_numpy(np.ascontiguousarray(tid_has_segs, dtype=np.int32)).to(dev)
+    c0 = torch.empty(max(n_rows, 1), dtype=torch.int32, device=dev)
+    c1 = torch.empty_like(c0)
+    e_key = torch.empty(2 * max(n_rows, 1), dtype=torch.int64, device=dev)
+    e_row = torch.empty(2 * max(n_rows, 1), dtype=torch.int32, device=dev)
+    ws_bytes = 48 * max(n_rows, 1) + (4 << 20)
+    n_ent = C.c_int32(0)
+    while True:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        rc = L.coral_hash_rows(n_rows, rows.data_ptr(), seg.shape[1], sg[0].data_ptr(), sg[1].data_ptr(), sg[2].data_ptr(),
+                               sg[3].data_ptr(), has.data_ptr(), len(tid_has_segs), ws.data_ptr(), ws_bytes, c0.data_ptr(),
+                               c1.data_ptr(), e_key.data_ptr(), e_row.data_ptr(), C.byref(n_ent), dr.stream())
+        if rc == -3:
+            ws_bytes = (int(n_ent.value) + 1) << 20
+            continue
+        break
+    if rc != 0:
+        raise _lib.CoralHipError("coral_hash_rows failed (%d): %s" % (rc, L.coral_sa_last_error().decode()))
+    k = int(n_ent.value)
+    return (c0[:n_rows].to(torch.int64).cpu().numpy(), c1[:n_rows].to(torch.int64).cpu().numpy(), e_key[:k].cpu().numpy(),
+            e_row[:k].to(torch.int64).cpu().numpy())
+
+
+def hash_rows(dr, T, seg, tid_has_segs):
+    return _hash_rows_local(dr, T, seg, tid_has_segs)

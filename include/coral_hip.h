@@ -131,6 +131,22 @@ int coral_sa_table(int32_t n_rec, const int32_t *rec_tid, const int32_t *rec_fla
 const char *coral_sa_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
+ * coral_hash_rows — hash_alignment_to_seg (/root/reference/src/infer_breakpoint_graph.py:181-210) on coral_sa_table's device
+ * rows: for both ends of every local alignment the index of the CN segment containing it (the reference's IntervalTree
+ * point queries), and the inverted index (contig, segment) -> alignments in the reference's append order.
+ *   inputs  rows int32[n_rows][8] (coral_sa_table layout); the CN segments as a device table sorted by (contig id, start),
+ *           pairwise disjoint: seg_tid / seg_start / seg_end (exclusive) / seg_idx (the segment's index within its contig,
+ *           file order) int32[n_seg]; tid_has_segs int32[n_tid] (0: contig absent from the CN file)
+ *   outputs cni0 / cni1 int32[n_rows] (-1 no segment, -3 contig absent); e_key int64[2 * n_rows] = contig << 32 | segment
+ *           ascending and e_row int32[2 * n_rows] = table row — the first *n_ent (HOST) entries are valid
+ * `workspace`: device scratch; too small -> CORAL_ERR_CAPACITY with *n_ent = MiB needed.  Synchronises `stream`.
+ * ------------------------------------------------------------------------------------------------ */
+int coral_hash_rows(int32_t n_rows, const int32_t *rows, int32_t n_seg, const int32_t *seg_tid, const int32_t *seg_start,
+                    const int32_t *seg_end, const int32_t *seg_idx, const int32_t *tid_has_segs, int32_t n_tid,
+                    void *workspace, int64_t workspace_bytes, int32_t *cni0, int32_t *cni1, int64_t *e_key, int32_t *e_row,
+                    int32_t *n_ent, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * coral_bp_pair_table — the breakpoint candidate of EVERY pair of local alignments of every chimeric read (K4).
  *
  * Replaces the arithmetic of alignment2bp (/root/reference/src/breakpoint_utilities.py:70-96, called per read inside the

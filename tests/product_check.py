@@ -239,8 +239,34 @@ def install_cpu_kernel_fakes(monkeypatch):
             rl[name_id_of[rn]] = v
         cols = np.ascontiguousarray(np.array(rows, dtype=np.int64).reshape(-1, 8).T)          # [8, n_rows], as the product's wrapper
         return (cols, np.array(off, dtype=np.int64), np.array(names, dtype=np.int64),
-                np.array(failed, dtype=bool), rl, pair_table_cpu(cols, off, h.chroms, dr.chr_rank))
+                np.array(failed, dtype=bool), rl, pair_table_cpu(cols, off, h.chroms, dr.chr_rank), None)
 
+    def hash_rows_local(dr, T, seg, tid_has_segs):
+        """coral_hash_rows stand-in: point queries by linear search over the segment table (the reference's IntervalTree
+        queries, ibg:190-191), entries appended alignment by alignment and stably sorted by (contig, segment)."""
+        segs_of = {}
+        for t, st, en, ix in seg.T.tolist():
+            segs_of.setdefault(t, []).append((st, en, ix))
+        c0 = np.full(T.n_rows, -3, dtype=np.int64)
+        c1 = np.full(T.n_rows, -3, dtype=np.int64)
+        entries = []
+        for r in range(T.n_rows):
+            t = int(T.tid[r])
+            if not tid_has_segs[t]:
+                continue
+            lo, hi = min(int(T.ra[r]), int(T.rb[r])), max(int(T.ra[r]), int(T.rb[r]))
+            hits = [[ix for st, en, ix in segs_of.get(t, ()) if st <= p < en] for p in (lo, hi)]
+            assert all(len(h) <= 1 for h in hits)
+            c0[r], c1[r] = (hits[0] or [-1])[0], (hits[1] or [-1])[0]
+            if c0[r] >= 0:
+                entries.append(((t << 32) | int(c0[r]), r))
+            if c1[r] >= 0 and c1[r] != c0[r]:
+                entries.append(((t << 32) | int(c1[r]), r))
+        entries.sort(key=lambda e: e[0])                      # stable
+        e = np.array(entries, dtype=np.int64).reshape(-1, 2)
+        return c0, c1, e[:, 0].copy(), e[:, 1].copy()
+
+    monkeypatch.setattr(kernels, "_hash_rows_local", hash_rows_local)
     monkeypatch.setattr(kernels, "_sa_table_local", sa_table_local)
     monkeypatch.setattr(kernels, "_scan_local", scan_local)
     monkeypatch.setattr(kernels, "_coverage_local", coverage_local)
