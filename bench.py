@@ -102,11 +102,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    step_ms = []
+    step_ms, phases = [], []
     for i in range(a.steps):
         ts = time.perf_counter()
         b = step(i)
         step_ms.append(round((time.perf_counter() - ts) * 1e3, 1))
+        phases.append(dict(ibg.PHASE_SECONDS))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -133,7 +134,8 @@ def main():
                        "generate_s": round(gen_s, 2), "step_ms": step_ms, "gc_policy": a.gc_policy,
                        "parallelism": ("%d independent samples, one per GPU" % world) if (a.mode == "samples" and world > 1)
                        else "records sharded over %d GPU(s)" % world,
-                       "phase_ms_last_step": {k: round(v * 1e3, 1) for k, v in ibg.PHASE_SECONDS.items()}},
+                       "phase_ms_median": {k: round(sorted(p.get(k, 0.0) for p in phases)[len(phases) // 2] * 1e3, 1)
+                                           for k in (phases[-1] if phases else {})}},
             "roofline": {"bound": "hbm", "kernel": SCAN_KERNEL_NAME.get(a.scan_variant, "variant %d" % a.scan_variant), "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": pmc_traffic(cfg, world, SCAN_KERNEL_NAME.get(a.scan_variant)), "launch_ms": scan_ms_avg,
                          "algorithmic_bytes_per_launch": int(alg_bytes_local)},

@@ -14,9 +14,11 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <unordered_map>
 #include <vector>
 
@@ -42,7 +44,12 @@ struct Search {
     std::vector<int64_t> order_off;                       // [n_groups + 1]
     std::vector<char> used;                               // scratch: per-read "pair k gave a candidate" flags
     char err[256] = "";
+    // CORAL_SEARCH_PROFILE=1: seconds per phase of coral_search_step and work counters, printed when the handle is freed
+    bool profile = false;
+    double t_reach = 0, t_plan = 0, t_union = 0, t_cand = 0;
+    long long n_steps = 0, n_visit = 0, n_adds = 0, n_keys = 0, n_union_items = 0;
 };
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 inline bool row_in(const Search &S, int64_t row, int64_t t, int64_t s, int64_t e) {
     // interval_overlap(rint, [chr, s, e]) with rint = [chr, ra, rb]; for '-' rows ra > rb, i.e. "interval contains the whole
@@ -78,10 +85,17 @@ extern "C" void *coral_search_create(int64_t n_reads, int64_t n_rows, const int6
     S->read_hash = read_hash; S->read_name = read_name; S->e_key = e_key; S->e_row = e_row; S->pairs = pairs;
     S->n_tid = n_tid; S->seg_off = seg_off; S->seg_start = seg_start; S->seg_end = seg_end;
     S->seen.assign((size_t)n_reads, 0u);
+    const char *pe = getenv("CORAL_SEARCH_PROFILE");
+    S->profile = pe && pe[0] == '1';
     return S;
 }
 
 extern "C" int coral_search_free(void *h) {
+    if (h && ((Search *)h)->profile) {
+        Search &S = *(Search *)h;
+        fprintf(stderr, "coral_search: %lld steps  reach %.2f ms (visit rows %lld, set adds %lld, keys %lld)  plan %.2f ms  union %.2f ms (%lld items)  candidates %.2f ms\n",
+                S.n_steps, S.t_reach * 1e3, S.n_visit, S.n_adds, S.n_keys, S.t_plan * 1e3, S.t_union * 1e3, S.n_union_items, S.t_cand * 1e3);
+    }
     delete (Search *)h;
     return CORAL_OK;
 }
@@ -112,6 +126,7 @@ extern "C" int coral_search_step(void *h, int64_t tid, int64_t s, int64_t e, int
     const int64_t *lo = std::lower_bound(S.e_key, S.e_key + S.n_ent, (tid << 32) + si);
     const int64_t *hi = std::lower_bound(S.e_key, S.e_key + S.n_ent, (tid << 32) + ei + 1);
     if (lo == hi) return CORAL_OK;
+    const double t0 = S.profile ? now_s() : 0.0;
     if (++S.stamp == 0) { std::fill(S.seen.begin(), S.seen.end(), 0u); S.stamp = 1; }
     std::vector<PySetEmu> sets;
     std::vector<int64_t> codes;                          // contig << 32 | segment, per key, in order of first appearance
@@ -129,6 +144,7 @@ extern "C" int coral_search_step(void *h, int64_t tid, int64_t s, int64_t e, int
             k = it->second;
         }
         sets[(size_t)k].add((int32_t)r, S.read_hash[r]);
+        ++S.n_adds;
     };
     for (const int64_t *v = lo; v < hi; ++v) {
         const int64_t row = S.e_row[v - S.e_key];
@@ -143,6 +159,7 @@ extern "C" int coral_search_step(void *h, int64_t tid, int64_t s, int64_t e, int
             if (c1 >= 0 && c1 != c0 && (other || c1 <= si || c1 >= ei)) add(t, c1, r);
         }
     }
+    const double t1 = S.profile ? now_s() : 0.0;
     // ---- contigs in order of first appearance; per contig the surviving segments ascending, cut into runs (ibg:385-419)
     std::vector<int64_t> contig_order;
     std::unordered_map<int64_t, std::vector<std::pair<int64_t, int32_t>>> bins_of;       // contig -> (segment, key)
@@ -182,9 +199,13 @@ extern "C" int coral_search_step(void *h, int64_t tid, int64_t s, int64_t e, int
     }
     // ---- per run: iteration order of  set() | sets[k0] | sets[k1] | ...  then alignment2bp of every read (bu:70-96)
     bool contigs_ok = true;
+    const double t2 = S.profile ? now_s() : 0.0;
+    double t_u = 0.0;
     for (const Run &run : plan) {
+        const double tu0 = S.profile ? now_s() : 0.0;
         PySetEmu acc;
         for (int32_t k : run.keys) acc.merge(sets[(size_t)k]);
+        if (S.profile) { t_u += now_s() - tu0; S.n_union_items += (long long)acc.used; }
         const int64_t t1 = run.t, s1 = S.seg_start[S.seg_off[run.t] + run.b0], e1 = S.seg_end[S.seg_off[run.t] + run.b1];
         const size_t cand_before = S.cand.size();
         for (size_t slot_e = 0; slot_e <= acc.mask; ++slot_e) {
@@ -213,6 +234,11 @@ extern "C" int coral_search_step(void *h, int64_t tid, int64_t s, int64_t e, int
         S.order_off.push_back((int64_t)S.order.size());
         const int64_t g[4] = {run.t, run.b0, run.b1, (int64_t)((S.cand.size() - cand_before) / 13)};
         S.groups.insert(S.groups.end(), g, g + 4);
+    }
+    if (S.profile) {
+        const double t3 = now_s();
+        S.t_reach += t1 - t0; S.t_plan += t2 - t1; S.t_union += t_u; S.t_cand += (t3 - t2) - t_u;
+        ++S.n_steps; S.n_visit += hi - lo; S.n_keys += (long long)codes.size();
     }
     if (!contigs_ok) { snprintf(S.err, sizeof(S.err), "search_step: contig outside chr1..22,X,Y,M"); return CORAL_ERR_FORMAT; }
     return CORAL_OK;
