@@ -60,8 +60,17 @@ def lib():
                                       C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.POINTER(C.c_int64)),
                                       C.POINTER(C.POINTER(C.c_int32))]
     L.coral_search_result.restype = C.c_int
-    L.coral_search_step.argtypes = [C.c_void_p] + [C.c_int64] * 5 + [C.c_double, C.c_int64]
+    L.coral_search_step.argtypes = [C.c_void_p] + [C.c_int64] * 5
     L.coral_search_step.restype = C.c_int
+    L.coral_search_prefetch.argtypes = [C.c_void_p] + [C.c_int64] * 5
+    L.coral_search_prefetch.restype = C.c_int
+    L.coral_search_params.argtypes = [C.c_void_p, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_int32]
+    L.coral_search_params.restype = C.c_int
+    L.coral_search_calls.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_int32)),
+                                     C.POINTER(C.c_int32)] + [C.POINTER(C.POINTER(C.c_int64))] * 3 + \
+        [C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int64)),
+         C.POINTER(C.POINTER(C.c_int64))]
+    L.coral_search_calls.restype = C.c_int
     L.coral_search_within.argtypes = [C.c_void_p, C.c_int32, P, P, P]
     L.coral_search_within.restype = C.c_int
     L.coral_search_between.argtypes = [C.c_void_p, C.c_int64, P] + [C.c_int64] * 6

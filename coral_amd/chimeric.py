@@ -174,12 +174,45 @@ class PairSearch:
             orders = [flat[off[g]:off[g + 1]].astype(np.int64) for g in range(ng.value)]
         return groups, out, orders
 
-    def step(self, tid, s, e, si, ei, min_cluster_cutoff, max_seq_len, want_orders=False):
+    def set_params(self, min_cluster_cutoff, max_seq_len, bp_distance_cutoff, match_cutoff, accept_floor, n_threads):
+        """Parameters of the build (ibg:385-391, :436-457) and the number of look-ahead threads; once, before the first step."""
+        self._lib.check(self._L.coral_search_params(self._h, float(min_cluster_cutoff), int(max_seq_len), int(bp_distance_cutoff),
+                                                    int(match_cutoff), float(accept_floor), int(n_threads)), "coral_search_params")
+
+    def prefetch(self, tid, s, e, si, ei):
+        """Have the step of interval (tid, s, e) on segments si..ei computed ahead on a worker thread (pure function)."""
+        self._lib.check(self._L.coral_search_prefetch(self._h, int(tid), int(s), int(e), int(si), int(ei)), "coral_search_prefetch")
+
+    def _calls(self, g):
+        """(cluster sizes, [(head, p1, p2, support index array, stats list)]) of run ``g`` — coral_call_breakpoints' result."""
+        C = self._C
+        ncl, nc = C.c_int32(0), C.c_int32(0)
+        csz, fl = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+        hd, p1, p2, so, si_ = (C.POINTER(C.c_int64)() for _ in range(5))
+        st = C.POINTER(C.c_double)()
+        self._lib.check(self._L.coral_search_calls(self._h, g, C.byref(ncl), C.byref(csz), C.byref(nc), C.byref(hd), C.byref(p1),
+                                                   C.byref(p2), C.byref(st), C.byref(fl), C.byref(so), C.byref(si_)), "coral_search_calls")
+        sizes = csz[:ncl.value]
+        calls = []
+        if nc.value:
+            off = so[:nc.value + 1]
+            sup_all = np.ctypeslib.as_array(si_, shape=(off[-1],)).copy() if off[-1] else np.zeros(0, dtype=np.int64)
+            for k in range(nc.value):
+                stats = st[6 * k:6 * k + 6]
+                if fl[k] & 1:
+                    stats[2] = 0                              # the reference's ValueError branch stores the integer 0
+                if fl[k] & 2:
+                    stats[3] = 0
+                calls.append((hd[k], p1[k], p2[k], sup_all[off[k]:off[k + 1]], stats))
+        return sizes, calls
+
+    def step(self, tid, s, e, si, ei, want_orders=False):
         """One step of the interval search for interval (tid, s, e) lying on segments si..ei: (groups int64 [G, 4] =
-        contig id, first segment, last segment, candidates; [Candidates per group]; [read order per group] or None)."""
-        self._check(self._L.coral_search_step(self._h, int(tid), int(s), int(e), int(si), int(ei), float(min_cluster_cutoff),
-                                              int(max_seq_len)), "coral_search_step")
-        return self._result(want_orders)
+        contig id, first segment, last segment, candidates; [Candidates per group]; [read order per group] or None;
+        [coral_call_breakpoints result per group])."""
+        self._check(self._L.coral_search_step(self._h, int(tid), int(s), int(e), int(si), int(ei)), "coral_search_step")
+        groups, cands, orders = self._result(want_orders)
+        return groups, cands, orders, [self._calls(g) if len(cands[g]) else ([], []) for g in range(len(cands))]
 
     def within(self, intervals) -> Candidates:
         """alignment2bp_l (bu:129-186) of every chimeric read, dict order, against [(tid, start, end)]."""

@@ -1,16 +1,19 @@
 // coral_search.cpp — host side of the amplicon-interval search (no device code).
 //
 // One step of the breadth-first search of find_interval_i (/root/reference/src/infer_breakpoint_graph.py:343-673) has a part
-// that is a pure function of the interval's coordinates (ibg:362-434):
+// that is a pure function of the interval's coordinates (ibg:362-457):
 //   * the CN segments reached from the interval through chimeric reads, each with the SET of read names that reach it
 //     (ibg:369-384) — sets of str whose iteration order later decides the order of the breakpoints;
 //   * segments with fewer reads than min_cluster_cutoff dropped (ibg:385-391), the rest grouped into runs of neighbouring
 //     segments whose sets are united with |= (ibg:392-419);
-//   * for every run, alignment2bp of every read of the united set against (run, interval) (ibg:428-434, bu:70-96).
-// coral_search_step does all of it in one call on index arrays: the sets are replayed with pyset_emu.h (no Python object is
-// created), and the candidates are FILTERED out of the pair table the GPU built once per graph build (k_bp_pairs in
-// coral_kernels.hip) — which pairs of a read's alignments fall into the two intervals is four comparisons per pair.
-// coral_search_within is the same filter for alignment2bp_l over all chimeric reads (find_breakpoints, ibg:676-690).
+//   * for every run, alignment2bp of every read of the united set against (run, interval) (ibg:428-434, bu:70-96);
+//   * cluster_bp_list + the bpc2bp loop over every run's candidates (ibg:436-457; coral_call_breakpoints).
+// Here that part is ONE native job on index arrays: the sets are replayed with pyset_emu.h (no Python object is created), the
+// candidates are FILTERED out of the pair table the GPU built once per graph build (k_bp_pairs in coral_kernels.hip: which
+// pairs of a read's alignments fall into the two intervals is four comparisons per pair), and because the job is pure it is
+// computed AHEAD on worker threads as soon as the caller knows an interval will be searched (coral_search_prefetch); the
+// order-dependent rest of the search (addbp, interval refinement) then finds the result ready (coral_search_step).
+// coral_search_within is the pair filter for alignment2bp_l over all chimeric reads (find_breakpoints, ibg:676-690).
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -18,7 +21,13 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -28,132 +37,201 @@
 namespace {
 using coral_detail::PySetEmu;
 
-struct Search {
-    int64_t n_reads = 0, n_rows = 0, n_ent = 0;
-    const int64_t *off = nullptr, *row_read = nullptr, *row_tid = nullptr, *ra = nullptr, *rb = nullptr, *cni0 = nullptr,
-                  *cni1 = nullptr, *read_hash = nullptr, *read_name = nullptr, *e_key = nullptr, *e_row = nullptr;
-    const int32_t *pairs = nullptr;                       // [2 * n_rows][8]  (k_bp_pairs)
-    int32_t n_tid = 0;
-    const int64_t *seg_off = nullptr, *seg_start = nullptr, *seg_end = nullptr;      // CN segments per contig, file order; end inclusive
-    std::vector<uint32_t> seen;                           // per read: stamp of the step that expanded it
-    uint32_t stamp = 0;
-    // results of the last call
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Per-read data packed for the two hot loops (reach sets, pair filter): one contiguous record per read instead of seven
+// parallel arrays, so a read costs one or two cache lines.  Record = {n rows, first table row} then per row
+// {contig, ra, rb, cni0, cni1, bits of pair (k, k + 1), bits of pair (k - 1, k + 1)}.
+struct PackedRow {
+    int32_t tid, ra, rb, cni0, cni1, bits_adj, bits_skip;
+};
+
+struct Calls {                                            // coral_call_breakpoints on one run's candidates
+    int32_t n_clusters = 0, n_calls = 0;
+    std::vector<int32_t> cluster_size, flags;
+    std::vector<int64_t> head, p1, p2, sup_off, sup_idx;
+    std::vector<double> stats;
+};
+
+struct StepResult {
+    int rc = CORAL_OK;
+    char err[200] = "";
     std::vector<int64_t> groups;                          // [n_groups][4]: contig id, first segment, last segment, candidates
     std::vector<int64_t> cand;                            // [K][13]: c1 p1 o1 c2 p2 o2 read(name id) i j gap swapped mqa mqb
     std::vector<int32_t> order;                           // reads (table index) of every run in set-iteration order
     std::vector<int64_t> order_off;                       // [n_groups + 1]
-    std::vector<char> used;                               // scratch: per-read "pair k gave a candidate" flags
-    char err[256] = "";
-    // CORAL_SEARCH_PROFILE=1: seconds per phase of coral_search_step and work counters, printed when the handle is freed
-    bool profile = false;
-    double t_reach = 0, t_plan = 0, t_union = 0, t_cand = 0;
-    long long n_steps = 0, n_visit = 0, n_adds = 0, n_keys = 0, n_union_items = 0;
+    std::vector<Calls> calls;                             // per run
+    void clear() {
+        rc = CORAL_OK; err[0] = 0;
+        groups.clear(); cand.clear(); order.clear(); order_off.assign(1, 0); calls.clear();
+    }
 };
-inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-inline bool row_in(const Search &S, int64_t row, int64_t t, int64_t s, int64_t e) {
+struct Scratch {                                          // per thread
+    std::vector<uint32_t> seen;                           // per read: stamp of the step that expanded it
+    uint32_t stamp = 0;
+    std::vector<char> used;
+};
+
+struct Entry {                                            // one (possibly pending) step in the cache
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false, taken = false;                     // taken: some thread is computing it
+    StepResult res;
+    int64_t key[5];
+};
+
+struct KeyHash {
+    size_t operator()(const std::array<int64_t, 5> &k) const {
+        uint64_t h = 0x9E3779B97F4A7C15ull;
+        for (int64_t v : k) { h ^= (uint64_t)v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); h *= 0xBF58476D1CE4E5B9ull; }
+        return (size_t)(h ^ (h >> 31));
+    }
+};
+
+struct Search {
+    int64_t n_reads = 0, n_rows = 0, n_ent = 0;
+    const int64_t *off = nullptr, *row_read = nullptr, *read_hash = nullptr, *read_name = nullptr, *e_key = nullptr, *e_row = nullptr;
+    const int32_t *pairs = nullptr;                       // [2 * n_rows][8]  (k_bp_pairs)
+    int32_t n_tid = 0;
+    const int64_t *seg_off = nullptr, *seg_start = nullptr, *seg_end = nullptr;      // CN segments per contig, file order; end inclusive
+    std::vector<int64_t> pack_off;                        // per read: index of its record in `pack` (in int32 units)
+    std::vector<int32_t> pack;
+    // parameters of the build (coral_search_params)
+    double min_cluster_cutoff = 3.0, accept_floor = 3.0;
+    int64_t max_seq_len = 2000000, bp_distance_cutoff = 2000, match_cutoff = 100;
+    // synchronous calls (within / between / inline steps) use these
+    Scratch main_scratch;
+    StepResult main_result;
+    const StepResult *current = nullptr;                  // what coral_search_result / coral_search_calls describe
+    std::shared_ptr<Entry> current_entry;
+    // look-ahead
+    std::vector<std::thread> workers;
+    std::mutex qm;
+    std::condition_variable qcv;
+    std::deque<std::shared_ptr<Entry>> queue;
+    std::unordered_map<std::array<int64_t, 5>, std::shared_ptr<Entry>, KeyHash> cache;
+    bool stop = false;
+    char err[256] = "";
+    // CORAL_SEARCH_PROFILE=1: seconds per phase and work counters over all steps, printed when the handle is freed
+    bool profile = false;
+    std::mutex pm;
+    double t_reach = 0, t_union = 0, t_cand = 0, t_call = 0, t_wait = 0;
+    long long n_steps = 0, n_visit = 0, n_adds = 0, n_keys = 0, n_union_items = 0, n_cand = 0, n_inline = 0;
+};
+
+inline const int32_t *rec_of(const Search &S, int64_t r) { return S.pack.data() + S.pack_off[(size_t)r]; }
+inline const PackedRow *rows_of(const int32_t *rec) { return reinterpret_cast<const PackedRow *>(rec + 2); }
+
+inline bool row_in(const PackedRow &w, int64_t t, int64_t s, int64_t e) {
     // interval_overlap(rint, [chr, s, e]) with rint = [chr, ra, rb]; for '-' rows ra > rb, i.e. "interval contains the whole
     // alignment" (bu:11-15)
-    return S.row_tid[row] == t && S.ra[row] <= e && s <= S.rb[row];
+    return w.tid == t && w.ra <= e && s <= w.rb;
 }
 
-inline bool emit(Search &S, int64_t slot, int64_t read) {
+inline bool emit(const Search &S, std::vector<int64_t> &cand, int64_t slot, int64_t read, int64_t base) {
     const int32_t *p = S.pairs + 8 * slot;
     const int32_t bits = p[5];
-    const int64_t base = S.off[read];
     const int64_t ia = p[6] - base, ib = p[7] - base;
     const bool swapped = (bits & 16) != 0;
     const int64_t row[13] = {p[0], p[1], (bits >> 2) & 1, p[2], p[3], (bits >> 3) & 1, S.read_name[read], swapped ? ib : ia,
                              swapped ? ia : ib, p[4], swapped ? 1 : 0, (bits >> 8) & 0xff, (bits >> 16) & 0xff};
-    S.cand.insert(S.cand.end(), row, row + 13);
+    cand.insert(cand.end(), row, row + 13);
     return (bits & 128) == 0;                  // false: a contig outside chr1..22,X,Y,M reaches interval2bp (KeyError, bu:293)
 }
-}  // namespace
 
-extern "C" void *coral_search_create(int64_t n_reads, int64_t n_rows, const int64_t *off, const int64_t *row_read,
-                                     const int64_t *row_tid, const int64_t *ra, const int64_t *rb, const int64_t *cni0,
-                                     const int64_t *cni1, const int64_t *read_hash, const int64_t *read_name, int64_t n_ent,
-                                     const int64_t *e_key, const int64_t *e_row, const int32_t *pairs, int32_t n_tid,
-                                     const int64_t *seg_off, const int64_t *seg_start, const int64_t *seg_end) {
-    if (n_reads < 0 || n_rows < 0 || n_ent < 0 || n_tid < 0 || !off || !seg_off) return nullptr;
-    if (n_rows > 0 && (!row_read || !row_tid || !ra || !rb || !cni0 || !cni1 || !pairs)) return nullptr;
-    if (n_reads > 0 && (!read_hash || !read_name)) return nullptr;
-    if (n_ent > 0 && (!e_key || !e_row)) return nullptr;
-    Search *S = new Search();
-    S->n_reads = n_reads; S->n_rows = n_rows; S->n_ent = n_ent;
-    S->off = off; S->row_read = row_read; S->row_tid = row_tid; S->ra = ra; S->rb = rb; S->cni0 = cni0; S->cni1 = cni1;
-    S->read_hash = read_hash; S->read_name = read_name; S->e_key = e_key; S->e_row = e_row; S->pairs = pairs;
-    S->n_tid = n_tid; S->seg_off = seg_off; S->seg_start = seg_start; S->seg_end = seg_end;
-    S->seen.assign((size_t)n_reads, 0u);
-    const char *pe = getenv("CORAL_SEARCH_PROFILE");
-    S->profile = pe && pe[0] == '1';
-    return S;
-}
-
-extern "C" int coral_search_free(void *h) {
-    if (h && ((Search *)h)->profile) {
-        Search &S = *(Search *)h;
-        fprintf(stderr, "coral_search: %lld steps  reach %.2f ms (visit rows %lld, set adds %lld, keys %lld)  plan %.2f ms  union %.2f ms (%lld items)  candidates %.2f ms\n",
-                S.n_steps, S.t_reach * 1e3, S.n_visit, S.n_adds, S.n_keys, S.t_plan * 1e3, S.t_union * 1e3, S.n_union_items, S.t_cand * 1e3);
+// alignment2bp (bu:70-96) of one read between intervals 1 and 2 (either order); appends to `cand`.
+inline bool pairs_between(const Search &S, Scratch &T, std::vector<int64_t> &cand, int64_t r, int64_t t1, int64_t s1, int64_t e1,
+                          int64_t t2, int64_t s2, int64_t e2) {
+    const int32_t *rec = rec_of(S, r);
+    const int64_t n = rec[0], base = rec[1];
+    if (n < 2) return true;
+    const PackedRow *w = rows_of(rec);
+    bool ok = true;
+    T.used.assign((size_t)n, 0);
+    for (int64_t k = 0; k + 1 < n; ++k) {                     // pairs (k, k + 1)
+        if (!(w[k].bits_adj & 2)) continue;
+        if ((row_in(w[k], t1, s1, e1) && row_in(w[k + 1], t2, s2, e2)) || (row_in(w[k + 1], t1, s1, e1) && row_in(w[k], t2, s2, e2))) {
+            T.used[(size_t)k] = 1;
+            ok &= emit(S, cand, 2 * (base + k), r, base);
+        }
     }
-    delete (Search *)h;
-    return CORAL_OK;
+    for (int64_t k = 1; k + 1 < n; ++k) {                     // pairs (k - 1, k + 1) around a low-MAPQ alignment
+        if (T.used[(size_t)k - 1] || T.used[(size_t)k]) continue;
+        if (!(w[k].bits_skip & 2)) continue;
+        if ((row_in(w[k - 1], t1, s1, e1) && row_in(w[k + 1], t2, s2, e2)) || (row_in(w[k + 1], t1, s1, e1) && row_in(w[k - 1], t2, s2, e2)))
+            ok &= emit(S, cand, 2 * (base + k) + 1, r, base);
+    }
+    return ok;
 }
 
-extern "C" const char *coral_search_error(void *h) { return h ? ((Search *)h)->err : "null handle"; }
-
-// Arrays of the last result (owned by the handle, valid until the next call on it).
-extern "C" int coral_search_result(void *h, int64_t *n_groups, const int64_t **groups, int64_t *n_cand, const int64_t **cand,
-                                   const int64_t **order_off, const int32_t **order) {
-    if (!h || !n_groups || !groups || !n_cand || !cand) return CORAL_ERR_ARG;
-    Search &S = *(Search *)h;
-    *n_groups = (int64_t)S.groups.size() / 4;
-    *groups = S.groups.data();
-    *n_cand = (int64_t)S.cand.size() / 13;
-    *cand = S.cand.data();
-    if (order_off) *order_off = S.order_off.data();
-    if (order) *order = S.order.data();
-    return CORAL_OK;
+void run_calls(const Search &S, const int64_t *cand, int64_t n, Calls &c) {
+    c = Calls();
+    if (n == 0) return;
+    const int64_t *ptr[13];
+    int64_t stride[13];
+    for (int f = 0; f < 13; ++f) { ptr[f] = cand + f; stride[f] = 13; }
+    c.cluster_size.resize((size_t)n); c.flags.resize((size_t)n);
+    c.head.resize((size_t)n); c.p1.resize((size_t)n); c.p2.resize((size_t)n);
+    c.sup_off.resize((size_t)n + 1); c.sup_idx.resize((size_t)n); c.stats.resize(6 * (size_t)n);
+    coral_call_breakpoints(n, ptr, stride, S.min_cluster_cutoff, S.bp_distance_cutoff, S.match_cutoff, S.accept_floor, 0,
+                           &c.n_clusters, c.cluster_size.data(), &c.n_calls, c.head.data(), c.p1.data(), c.p2.data(), c.stats.data(),
+                           c.flags.data(), c.sup_off.data(), c.sup_idx.data());
 }
 
-extern "C" int coral_search_step(void *h, int64_t tid, int64_t s, int64_t e, int64_t si, int64_t ei, double min_cluster_cutoff,
-                                 int64_t max_seq_len) {
-    if (!h) return CORAL_ERR_ARG;
-    Search &S = *(Search *)h;
-    S.groups.clear(); S.cand.clear(); S.order.clear(); S.order_off.assign(1, 0);
-    if (tid < 0 || tid >= S.n_tid) { snprintf(S.err, sizeof(S.err), "search_step: contig id out of range"); return CORAL_ERR_ARG; }
+void compute_step(Search &S, Scratch &T, const int64_t key[5], StepResult &R) {
+    const int64_t tid = key[0], s = key[1], e = key[2], si = key[3], ei = key[4];
+    R.clear();
+    auto fail = [&](int rc, const char *msg) { R.rc = rc; snprintf(R.err, sizeof(R.err), "%s", msg); };
+    if (tid < 0 || tid >= S.n_tid) return fail(CORAL_ERR_ARG, "search_step: contig id out of range");
     // ---- reads hashed to segments si..ei of the contig, in the reference's visiting order (segment, then append order)
     const int64_t *lo = std::lower_bound(S.e_key, S.e_key + S.n_ent, (tid << 32) + si);
     const int64_t *hi = std::lower_bound(S.e_key, S.e_key + S.n_ent, (tid << 32) + ei + 1);
-    if (lo == hi) return CORAL_OK;
+    if (lo == hi) return;
     const double t0 = S.profile ? now_s() : 0.0;
-    if (++S.stamp == 0) { std::fill(S.seen.begin(), S.seen.end(), 0u); S.stamp = 1; }
+    if (T.seen.size() != (size_t)S.n_reads) { T.seen.assign((size_t)S.n_reads, 0u); T.stamp = 0; }
+    if (++T.stamp == 0) { std::fill(T.seen.begin(), T.seen.end(), 0u); T.stamp = 1; }
     std::vector<PySetEmu> sets;
     std::vector<int64_t> codes;                          // contig << 32 | segment, per key, in order of first appearance
     std::unordered_map<int64_t, int32_t> key_of;
+    long long n_adds = 0;
+    int64_t last_code = -1;
+    int32_t last_key = -1;
     auto add = [&](int64_t t, int64_t c, int64_t r) {
         const int64_t code = (t << 32) | c;
-        auto it = key_of.find(code);
         int32_t k;
-        if (it == key_of.end()) {
-            k = (int32_t)sets.size();
-            key_of.emplace(code, k);
-            sets.emplace_back();
-            codes.push_back(code);
+        if (code == last_code) {
+            k = last_key;
         } else {
-            k = it->second;
+            auto it = key_of.find(code);
+            if (it == key_of.end()) {
+                k = (int32_t)sets.size();
+                key_of.emplace(code, k);
+                sets.emplace_back();
+                codes.push_back(code);
+            } else {
+                k = it->second;
+            }
+            last_code = code;
+            last_key = k;
         }
         sets[(size_t)k].add((int32_t)r, S.read_hash[r]);
-        ++S.n_adds;
+        ++n_adds;
     };
-    for (const int64_t *v = lo; v < hi; ++v) {
-        const int64_t row = S.e_row[v - S.e_key];
-        if (row < 0 || row >= S.n_rows) { snprintf(S.err, sizeof(S.err), "search_step: row out of range"); return CORAL_ERR_ARG; }
+    const int64_t *rows_e = S.e_row + (lo - S.e_key);
+    const int64_t n_visit = hi - lo;
+    for (int64_t v = 0; v < n_visit; ++v) {
+        if (v + 8 < n_visit) __builtin_prefetch(&S.row_read[rows_e[v + 8]]);
+        const int64_t row = rows_e[v];
+        if (row < 0 || row >= S.n_rows) return fail(CORAL_ERR_ARG, "search_step: row out of range");
         const int64_t r = S.row_read[row];
-        if (S.seen[(size_t)r] == S.stamp) continue;
-        S.seen[(size_t)r] = S.stamp;
-        for (int64_t k = S.off[r]; k < S.off[r + 1]; ++k) {
-            const int64_t t = S.row_tid[k], c0 = S.cni0[k], c1 = S.cni1[k];
+        if (T.seen[(size_t)r] == T.stamp) continue;
+        T.seen[(size_t)r] = T.stamp;
+        const int32_t *rec = rec_of(S, r);
+        const int64_t n = rec[0];
+        const PackedRow *w = rows_of(rec);
+        for (int64_t k = 0; k < n; ++k) {
+            const int64_t t = w[k].tid, c0 = w[k].cni0, c1 = w[k].cni1;
             const bool other = t != tid;
             if (c0 >= 0 && (other || c0 <= si || c0 >= ei)) add(t, c0, r);              // Q9: the boundary segments count as outside
             if (c1 >= 0 && c1 != c0 && (other || c1 <= si || c1 >= ei)) add(t, c1, r);
@@ -170,14 +248,14 @@ extern "C" int coral_search_step(void *h, int64_t tid, int64_t s, int64_t e, int
             contig_order.push_back(t);
             it = bins_of.emplace(t, std::vector<std::pair<int64_t, int32_t>>()).first;
         }
-        if (!((double)sets[k].used < min_cluster_cutoff)) it->second.emplace_back(codes[k] & 0xFFFFFFFFLL, (int32_t)k);
+        if (!((double)sets[k].used < S.min_cluster_cutoff)) it->second.emplace_back(codes[k] & 0xFFFFFFFFLL, (int32_t)k);
     }
     struct Run { int64_t t, b0, b1; std::vector<int32_t> keys; };
     std::vector<Run> plan;
     for (int64_t t : contig_order) {
         auto &bins = bins_of[t];
         if (bins.empty()) continue;
-        if (t < 0 || t >= S.n_tid) { snprintf(S.err, sizeof(S.err), "search_step: contig id out of range"); return CORAL_ERR_ARG; }
+        if (t < 0 || t >= S.n_tid) return fail(CORAL_ERR_ARG, "search_step: contig id out of range");
         std::sort(bins.begin(), bins.end());
         const int64_t *st = S.seg_start + S.seg_off[t], *en = S.seg_end + S.seg_off[t];
         const int64_t n_seg = S.seg_off[t + 1] - S.seg_off[t];
@@ -185,8 +263,8 @@ extern "C" int coral_search_step(void *h, int64_t tid, int64_t s, int64_t e, int
         for (size_t k = 0; k + 1 < bins.size(); ++k) {
             cur.keys.push_back(bins[k].second);
             const int64_t a = bins[k].first, b = bins[k + 1].first;
-            if (a >= n_seg || b >= n_seg) { snprintf(S.err, sizeof(S.err), "search_step: segment index out of range"); return CORAL_ERR_ARG; }
-            if (b - a > 2 || st[b] - en[a] > max_seq_len) {
+            if (a >= n_seg || b >= n_seg) return fail(CORAL_ERR_ARG, "search_step: segment index out of range");
+            if (b - a > 2 || st[b] - en[a] > S.max_seq_len) {
                 cur.b1 = a;
                 plan.push_back(cur);
                 cur = Run{t, b, b, {}};
@@ -194,53 +272,233 @@ extern "C" int coral_search_step(void *h, int64_t tid, int64_t s, int64_t e, int
         }
         cur.keys.push_back(bins.back().second);
         cur.b1 = bins.back().first;
-        if (cur.b1 >= n_seg) { snprintf(S.err, sizeof(S.err), "search_step: segment index out of range"); return CORAL_ERR_ARG; }
+        if (cur.b1 >= n_seg || cur.b0 >= n_seg) return fail(CORAL_ERR_ARG, "search_step: segment index out of range");
         plan.push_back(cur);
     }
     // ---- per run: iteration order of  set() | sets[k0] | sets[k1] | ...  then alignment2bp of every read (bu:70-96)
     bool contigs_ok = true;
-    const double t2 = S.profile ? now_s() : 0.0;
-    double t_u = 0.0;
-    for (const Run &run : plan) {
+    double t_u = 0.0, t_c = 0.0;
+    long long n_items = 0;
+    R.calls.resize(plan.size());
+    for (size_t g = 0; g < plan.size(); ++g) {
+        const Run &run = plan[g];
         const double tu0 = S.profile ? now_s() : 0.0;
         PySetEmu acc;
         for (int32_t k : run.keys) acc.merge(sets[(size_t)k]);
-        if (S.profile) { t_u += now_s() - tu0; S.n_union_items += (long long)acc.used; }
-        const int64_t t1 = run.t, s1 = S.seg_start[S.seg_off[run.t] + run.b0], e1 = S.seg_end[S.seg_off[run.t] + run.b1];
-        const size_t cand_before = S.cand.size();
-        for (size_t slot_e = 0; slot_e <= acc.mask; ++slot_e) {
-            const int32_t r = acc.key[slot_e];
-            if (r < 0) continue;
-            S.order.push_back(r);
-            const int64_t base = S.off[r], n = S.off[r + 1] - base;
-            if (n < 2) continue;
-            S.used.assign((size_t)n, 0);
-            for (int64_t k = 0; k + 1 < n; ++k) {                     // pairs (k, k + 1)
-                const int64_t a = base + k, b = a + 1;
-                if (!(S.pairs[8 * (2 * a) + 5] & 2)) continue;
-                if ((row_in(S, a, t1, s1, e1) && row_in(S, b, tid, s, e)) || (row_in(S, b, t1, s1, e1) && row_in(S, a, tid, s, e))) {
-                    S.used[(size_t)k] = 1;
-                    contigs_ok &= emit(S, 2 * a, r);
-                }
-            }
-            for (int64_t k = 1; k + 1 < n; ++k) {                     // pairs (k - 1, k + 1) around a low-MAPQ alignment
-                if (S.used[(size_t)k - 1] || S.used[(size_t)k]) continue;
-                const int64_t m = base + k, a = m - 1, b = m + 1;
-                if (!(S.pairs[8 * (2 * m + 1) + 5] & 2)) continue;
-                if ((row_in(S, a, t1, s1, e1) && row_in(S, b, tid, s, e)) || (row_in(S, b, t1, s1, e1) && row_in(S, a, tid, s, e)))
-                    contigs_ok &= emit(S, 2 * m + 1, r);
-            }
+        const double tu1 = S.profile ? now_s() : 0.0;
+        n_items += (long long)acc.used;
+        const int64_t t1_ = run.t, s1 = S.seg_start[S.seg_off[run.t] + run.b0], e1 = S.seg_end[S.seg_off[run.t] + run.b1];
+        const size_t cand_before = R.cand.size(), order_before = R.order.size();
+        R.order.reserve(order_before + acc.used);
+        for (size_t slot_e = 0; slot_e <= acc.mask; ++slot_e)
+            if (acc.key[slot_e] >= 0) R.order.push_back(acc.key[slot_e]);
+        const int32_t *ord = R.order.data() + order_before;
+        const size_t n_ord = R.order.size() - order_before;
+        for (size_t q = 0; q < n_ord; ++q) {
+            if (q + 6 < n_ord) __builtin_prefetch(S.pack.data() + S.pack_off[(size_t)ord[q + 6]]);
+            contigs_ok &= pairs_between(S, T, R.cand, ord[q], t1_, s1, e1, tid, s, e);
         }
-        S.order_off.push_back((int64_t)S.order.size());
-        const int64_t g[4] = {run.t, run.b0, run.b1, (int64_t)((S.cand.size() - cand_before) / 13)};
-        S.groups.insert(S.groups.end(), g, g + 4);
+        R.order_off.push_back((int64_t)R.order.size());
+        const int64_t n_c = (int64_t)((R.cand.size() - cand_before) / 13);
+        const int64_t gr[4] = {run.t, run.b0, run.b1, n_c};
+        R.groups.insert(R.groups.end(), gr, gr + 4);
+        const double tu2 = S.profile ? now_s() : 0.0;
+        t_u += tu1 - tu0;
+        t_c += tu2 - tu1;
+    }
+    const double t2 = S.profile ? now_s() : 0.0;
+    if (!contigs_ok) return fail(CORAL_ERR_FORMAT, "search_step: contig outside chr1..22,X,Y,M");
+    // ---- cluster_bp_list + the bpc2bp loop of every run (ibg:436-457: the sub-cluster counter never advances there, Q4)
+    {
+        int64_t at = 0;
+        for (size_t g = 0; g < plan.size(); ++g) {
+            const int64_t n_c = R.groups[4 * g + 3];
+            run_calls(S, R.cand.data() + 13 * at, n_c, R.calls[g]);
+            at += n_c;
+        }
     }
     if (S.profile) {
         const double t3 = now_s();
-        S.t_reach += t1 - t0; S.t_plan += t2 - t1; S.t_union += t_u; S.t_cand += (t3 - t2) - t_u;
-        ++S.n_steps; S.n_visit += hi - lo; S.n_keys += (long long)codes.size();
+        std::lock_guard<std::mutex> lk(S.pm);
+        S.t_reach += t1 - t0; S.t_union += t_u; S.t_cand += t_c; S.t_call += t3 - t2;
+        ++S.n_steps; S.n_visit += n_visit; S.n_adds += n_adds; S.n_keys += (long long)codes.size(); S.n_union_items += n_items;
+        S.n_cand += (long long)(R.cand.size() / 13);
     }
-    if (!contigs_ok) { snprintf(S.err, sizeof(S.err), "search_step: contig outside chr1..22,X,Y,M"); return CORAL_ERR_FORMAT; }
+}
+
+void worker_main(Search *S) {
+    Scratch T;
+    for (;;) {
+        std::shared_ptr<Entry> e;
+        {
+            std::unique_lock<std::mutex> lk(S->qm);
+            S->qcv.wait(lk, [&] { return S->stop || !S->queue.empty(); });
+            if (S->stop) return;
+            e = S->queue.front();
+            S->queue.pop_front();
+        }
+        {
+            std::lock_guard<std::mutex> lk(e->m);
+            if (e->taken) continue;                      // the caller got there first and computes it itself
+            e->taken = true;
+        }
+        compute_step(*S, T, e->key, e->res);
+        {
+            std::lock_guard<std::mutex> lk(e->m);
+            e->done = true;
+        }
+        e->cv.notify_all();
+    }
+}
+}  // namespace
+
+extern "C" void *coral_search_create(int64_t n_reads, int64_t n_rows, const int64_t *off, const int64_t *row_read,
+                                     const int64_t *row_tid, const int64_t *ra, const int64_t *rb, const int64_t *cni0,
+                                     const int64_t *cni1, const int64_t *read_hash, const int64_t *read_name, int64_t n_ent,
+                                     const int64_t *e_key, const int64_t *e_row, const int32_t *pairs, int32_t n_tid,
+                                     const int64_t *seg_off, const int64_t *seg_start, const int64_t *seg_end) {
+    if (n_reads < 0 || n_rows < 0 || n_ent < 0 || n_tid < 0 || !off || !seg_off) return nullptr;
+    if (n_rows > 0 && (!row_read || !row_tid || !ra || !rb || !cni0 || !cni1 || !pairs)) return nullptr;
+    if (n_reads > 0 && (!read_hash || !read_name)) return nullptr;
+    if (n_ent > 0 && (!e_key || !e_row)) return nullptr;
+    Search *S = new Search();
+    S->n_reads = n_reads; S->n_rows = n_rows; S->n_ent = n_ent;
+    S->off = off; S->row_read = row_read; S->read_hash = read_hash; S->read_name = read_name; S->e_key = e_key; S->e_row = e_row;
+    S->pairs = pairs; S->n_tid = n_tid; S->seg_off = seg_off; S->seg_start = seg_start; S->seg_end = seg_end;
+    S->pack_off.resize((size_t)n_reads);
+    S->pack.reserve((size_t)(2 * n_reads + 7 * n_rows));
+    for (int64_t r = 0; r < n_reads; ++r) {
+        const int64_t base = off[r], n = off[r + 1] - base;
+        if (n < 0 || base < 0 || base + n > n_rows) { delete S; return nullptr; }
+        S->pack_off[(size_t)r] = (int64_t)S->pack.size();
+        S->pack.push_back((int32_t)n);
+        S->pack.push_back((int32_t)base);
+        for (int64_t k = base; k < base + n; ++k) {
+            const int32_t w[7] = {(int32_t)row_tid[k], (int32_t)ra[k], (int32_t)rb[k], (int32_t)cni0[k], (int32_t)cni1[k],
+                                  pairs[8 * (2 * k) + 5], pairs[8 * (2 * k + 1) + 5]};
+            S->pack.insert(S->pack.end(), w, w + 7);
+        }
+    }
+    const char *pe = getenv("CORAL_SEARCH_PROFILE");
+    S->profile = pe && pe[0] == '1';
+    S->main_result.clear();
+    S->current = &S->main_result;
+    return S;
+}
+
+// Parameters of the build + the number of look-ahead threads (0 = every step is computed by the caller).
+extern "C" int coral_search_params(void *h, double min_cluster_cutoff, int64_t max_seq_len, int64_t bp_distance_cutoff,
+                                   int64_t match_cutoff, double accept_floor, int32_t n_threads) {
+    if (!h || bp_distance_cutoff <= 0 || n_threads < 0 || n_threads > 64) return CORAL_ERR_ARG;
+    Search &S = *(Search *)h;
+    if (!S.workers.empty() || !S.cache.empty()) return CORAL_ERR_ARG;          // set once, before the first step
+    S.min_cluster_cutoff = min_cluster_cutoff; S.max_seq_len = max_seq_len; S.bp_distance_cutoff = bp_distance_cutoff;
+    S.match_cutoff = match_cutoff; S.accept_floor = accept_floor;
+    for (int32_t k = 0; k < n_threads; ++k) S.workers.emplace_back(worker_main, &S);
+    return CORAL_OK;
+}
+
+extern "C" int coral_search_free(void *h) {
+    if (!h) return CORAL_OK;
+    Search &S = *(Search *)h;
+    {
+        std::lock_guard<std::mutex> lk(S.qm);
+        S.stop = true;
+    }
+    S.qcv.notify_all();
+    for (std::thread &t : S.workers) t.join();
+    if (S.profile)
+        fprintf(stderr, "coral_search: %lld steps (%lld computed by the caller, waited %.2f ms)  reach %.2f ms (visit rows %lld, set adds %lld, "
+                "keys %lld)  union %.2f ms (%lld items)  candidates %.2f ms (%lld)  calls %.2f ms\n",
+                S.n_steps, S.n_inline, S.t_wait * 1e3, S.t_reach * 1e3, S.n_visit, S.n_adds, S.n_keys, S.t_union * 1e3, S.n_union_items,
+                S.t_cand * 1e3, S.n_cand, S.t_call * 1e3);
+    delete &S;
+    return CORAL_OK;
+}
+
+extern "C" const char *coral_search_error(void *h) { return h ? ((Search *)h)->err : "null handle"; }
+
+// Ask for the step of interval (tid, s, e) on segments si..ei to be computed ahead (no-op without worker threads).
+extern "C" int coral_search_prefetch(void *h, int64_t tid, int64_t s, int64_t e, int64_t si, int64_t ei) {
+    if (!h) return CORAL_ERR_ARG;
+    Search &S = *(Search *)h;
+    if (S.workers.empty()) return CORAL_OK;
+    const std::array<int64_t, 5> key = {tid, s, e, si, ei};
+    std::lock_guard<std::mutex> lk(S.qm);
+    if (S.cache.find(key) != S.cache.end()) return CORAL_OK;
+    auto ent = std::make_shared<Entry>();
+    memcpy(ent->key, key.data(), sizeof(ent->key));
+    S.cache.emplace(key, ent);
+    S.queue.push_back(ent);
+    S.qcv.notify_one();
+    return CORAL_OK;
+}
+
+extern "C" int coral_search_step(void *h, int64_t tid, int64_t s, int64_t e, int64_t si, int64_t ei) {
+    if (!h) return CORAL_ERR_ARG;
+    Search &S = *(Search *)h;
+    const std::array<int64_t, 5> key = {tid, s, e, si, ei};
+    std::shared_ptr<Entry> ent;
+    {
+        std::lock_guard<std::mutex> lk(S.qm);
+        auto it = S.cache.find(key);
+        if (it != S.cache.end()) ent = it->second;
+    }
+    S.current_entry.reset();
+    if (ent) {
+        bool mine = false;
+        {
+            std::unique_lock<std::mutex> lk(ent->m);
+            if (!ent->taken) { ent->taken = true; mine = true; }           // still queued: do it here, the worker will skip it
+        }
+        if (mine) {
+            compute_step(S, S.main_scratch, ent->key, ent->res);
+            std::lock_guard<std::mutex> lk(ent->m);
+            ent->done = true;
+            ++S.n_inline;
+        } else {
+            const double w0 = S.profile ? now_s() : 0.0;
+            std::unique_lock<std::mutex> lk(ent->m);
+            ent->cv.wait(lk, [&] { return ent->done; });
+            if (S.profile) S.t_wait += now_s() - w0;
+        }
+        S.current_entry = ent;
+        S.current = &ent->res;
+    } else {
+        compute_step(S, S.main_scratch, key.data(), S.main_result);
+        ++S.n_inline;
+        S.current = &S.main_result;
+    }
+    if (S.current->rc != CORAL_OK) snprintf(S.err, sizeof(S.err), "%s", S.current->err);
+    return S.current->rc;
+}
+
+// Arrays of the last result (owned by the handle, valid until the next step / within / between call on it).
+extern "C" int coral_search_result(void *h, int64_t *n_groups, const int64_t **groups, int64_t *n_cand, const int64_t **cand,
+                                   const int64_t **order_off, const int32_t **order) {
+    if (!h || !n_groups || !groups || !n_cand || !cand) return CORAL_ERR_ARG;
+    const StepResult &R = *((Search *)h)->current;
+    *n_groups = (int64_t)R.groups.size() / 4;
+    *groups = R.groups.data();
+    *n_cand = (int64_t)R.cand.size() / 13;
+    *cand = R.cand.data();
+    if (order_off) *order_off = R.order_off.data();
+    if (order) *order = R.order.data();
+    return CORAL_OK;
+}
+
+// coral_call_breakpoints' outputs for run `g` of the last coral_search_step (same meaning as that function's arguments).
+extern "C" int coral_search_calls(void *h, int64_t g, int32_t *n_clusters, const int32_t **cluster_size, int32_t *n_calls,
+                                  const int64_t **head, const int64_t **p1, const int64_t **p2, const double **stats,
+                                  const int32_t **flags, const int64_t **sup_off, const int64_t **sup_idx) {
+    if (!h || !n_clusters || !cluster_size || !n_calls || !head || !p1 || !p2 || !stats || !flags || !sup_off || !sup_idx)
+        return CORAL_ERR_ARG;
+    const StepResult &R = *((Search *)h)->current;
+    if (g < 0 || (size_t)g >= R.calls.size()) return CORAL_ERR_ARG;
+    const Calls &c = R.calls[(size_t)g];
+    *n_clusters = c.n_clusters; *cluster_size = c.cluster_size.data(); *n_calls = c.n_calls;
+    *head = c.head.data(); *p1 = c.p1.data(); *p2 = c.p2.data(); *stats = c.stats.data(); *flags = c.flags.data();
+    *sup_off = c.sup_off.data(); *sup_idx = c.sup_idx.data();
     return CORAL_OK;
 }
 
@@ -250,79 +508,71 @@ extern "C" int coral_search_step(void *h, int64_t tid, int64_t s, int64_t e, int
 extern "C" int coral_search_within(void *h, int32_t n_int, const int64_t *int_tid, const int64_t *int_start, const int64_t *int_end) {
     if (!h || n_int < 0 || (n_int > 0 && (!int_tid || !int_start || !int_end))) return CORAL_ERR_ARG;
     Search &S = *(Search *)h;
-    S.groups.clear(); S.cand.clear(); S.order.clear(); S.order_off.assign(1, 0);
+    StepResult &R = S.main_result;
+    R.clear();
+    S.current = &R;
+    S.current_entry.reset();
     std::vector<std::vector<int32_t>> by_tid((size_t)S.n_tid);              // interval indices per contig, list order kept
     for (int32_t k = 0; k < n_int; ++k)
         if (int_tid[k] >= 0 && int_tid[k] < S.n_tid) by_tid[(size_t)int_tid[k]].push_back(k);
-    auto first_interval = [&](int64_t row) -> int32_t {
-        const int64_t t = S.row_tid[row];
-        if (t < 0 || t >= S.n_tid) return -1;
-        for (int32_t k : by_tid[(size_t)t])
-            if (S.ra[row] <= int_end[k] && int_start[k] <= S.rb[row]) return k;
+    auto first_interval = [&](const PackedRow &w) -> int32_t {
+        if (w.tid < 0 || w.tid >= S.n_tid) return -1;
+        for (int32_t k : by_tid[(size_t)w.tid])
+            if (w.ra <= int_end[k] && int_start[k] <= w.rb) return k;
         return -1;
     };
     bool contigs_ok = true;
     std::vector<int32_t> fi;
+    std::vector<char> &used = S.main_scratch.used;
     for (int64_t r = 0; r < S.n_reads; ++r) {
-        const int64_t base = S.off[r], n = S.off[r + 1] - base;
+        const int32_t *rec = rec_of(S, r);
+        const int64_t n = rec[0], base = rec[1];
         if (n < 2) continue;
+        const PackedRow *w = rows_of(rec);
         fi.resize((size_t)n);
-        for (int64_t k = 0; k < n; ++k) fi[(size_t)k] = first_interval(base + k);
-        S.used.assign((size_t)n, 0);
+        for (int64_t k = 0; k < n; ++k) fi[(size_t)k] = first_interval(w[k]);
+        used.assign((size_t)n, 0);
         for (int64_t k = 0; k + 1 < n; ++k) {
-            const int32_t bits = S.pairs[8 * (2 * (base + k)) + 5];
+            const int32_t bits = w[k].bits_adj;
             if (!(bits & 2) || fi[(size_t)k] < 0 || fi[(size_t)k] != fi[(size_t)k + 1]) continue;
             if ((bits & 32) || (bits & 64)) {
-                S.used[(size_t)k] = 1;
-                contigs_ok &= emit(S, 2 * (base + k), r);
+                used[(size_t)k] = 1;
+                contigs_ok &= emit(S, R.cand, 2 * (base + k), r, base);
             }
         }
         for (int64_t k = 1; k + 1 < n; ++k) {
-            if (S.used[(size_t)k - 1] || S.used[(size_t)k]) continue;
-            const int32_t bits = S.pairs[8 * (2 * (base + k) + 1) + 5];
+            if (used[(size_t)k - 1] || used[(size_t)k]) continue;
+            const int32_t bits = w[k].bits_skip;
             if (!(bits & 2) || fi[(size_t)k - 1] < 0 || fi[(size_t)k - 1] != fi[(size_t)k + 1]) continue;
-            if ((bits & 32) || (bits & 64)) contigs_ok &= emit(S, 2 * (base + k) + 1, r);
+            if ((bits & 32) || (bits & 64)) contigs_ok &= emit(S, R.cand, 2 * (base + k) + 1, r, base);
         }
     }
-    const int64_t g[4] = {-1, -1, -1, (int64_t)(S.cand.size() / 13)};
-    S.groups.insert(S.groups.end(), g, g + 4);
-    S.order_off.push_back(0);
+    const int64_t g[4] = {-1, -1, -1, (int64_t)(R.cand.size() / 13)};
+    R.groups.insert(R.groups.end(), g, g + 4);
+    R.order_off.push_back(0);
     if (!contigs_ok) { snprintf(S.err, sizeof(S.err), "search_within: contig outside chr1..22,X,Y,M"); return CORAL_ERR_FORMAT; }
     return CORAL_OK;
 }
 
-// alignment2bp (bu:70-96) of the given reads between two intervals — the single query coral_search_step runs per run;
+// alignment2bp (bu:70-96) of the given reads between two intervals — the single query a search step runs per run;
 // exported for the unit tests against the reference's own vectors and for callers that keep the reference's loop.
 extern "C" int coral_search_between(void *h, int64_t n_sel, const int32_t *reads, int64_t t1, int64_t s1, int64_t e1, int64_t t2,
                                     int64_t s2, int64_t e2) {
     if (!h || n_sel < 0 || (n_sel > 0 && !reads)) return CORAL_ERR_ARG;
     Search &S = *(Search *)h;
-    S.groups.clear(); S.cand.clear(); S.order.clear(); S.order_off.assign(1, 0);
+    StepResult &R = S.main_result;
+    R.clear();
+    S.current = &R;
+    S.current_entry.reset();
     bool contigs_ok = true;
     for (int64_t q = 0; q < n_sel; ++q) {
         const int64_t r = reads[q];
         if (r < 0 || r >= S.n_reads) { snprintf(S.err, sizeof(S.err), "search_between: read index out of range"); return CORAL_ERR_ARG; }
-        const int64_t base = S.off[r], n = S.off[r + 1] - base;
-        if (n < 2) continue;
-        S.used.assign((size_t)n, 0);
-        for (int64_t k = 0; k + 1 < n; ++k) {
-            const int64_t a = base + k, b = a + 1;
-            if (!(S.pairs[8 * (2 * a) + 5] & 2)) continue;
-            if ((row_in(S, a, t1, s1, e1) && row_in(S, b, t2, s2, e2)) || (row_in(S, b, t1, s1, e1) && row_in(S, a, t2, s2, e2))) {
-                S.used[(size_t)k] = 1;
-                contigs_ok &= emit(S, 2 * a, r);
-            }
-        }
-        for (int64_t k = 1; k + 1 < n; ++k) {
-            if (S.used[(size_t)k - 1] || S.used[(size_t)k]) continue;
-            const int64_t m = base + k, a = m - 1, b = m + 1;
-            if (!(S.pairs[8 * (2 * m + 1) + 5] & 2)) continue;
-            if ((row_in(S, a, t1, s1, e1) && row_in(S, b, t2, s2, e2)) || (row_in(S, b, t1, s1, e1) && row_in(S, a, t2, s2, e2)))
-                contigs_ok &= emit(S, 2 * m + 1, r);
-        }
+        contigs_ok &= pairs_between(S, S.main_scratch, R.cand, r, t1, s1, e1, t2, s2, e2);
     }
-    const int64_t g[4] = {t1, -1, -1, (int64_t)(S.cand.size() / 13)};
-    S.groups.insert(S.groups.end(), g, g + 4);
+    const int64_t g[4] = {t1, -1, -1, (int64_t)(R.cand.size() / 13)};
+    R.groups.insert(R.groups.end(), g, g + 4);
+    R.order_off.push_back(0);
     if (!contigs_ok) { snprintf(S.err, sizeof(S.err), "search_between: contig outside chr1..22,X,Y,M"); return CORAL_ERR_FORMAT; }
     return CORAL_OK;
 }

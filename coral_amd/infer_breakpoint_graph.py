@@ -427,6 +427,9 @@ class bam_to_breakpoint_nanopore():
                 iv[2] = by[c][rcni][2] + self.interval_delta
         ccid = 0
         _lib.check_pyset_replay()            # once per process: the set replay must match this interpreter's sets
+        if len(self._chim.read):
+            for ai in range(len(self.amplicon_intervals)):
+                self._prefetch_step(ai)
         for ai in range(len(self.amplicon_intervals)):
             if self.amplicon_intervals[ai][3] == -1:
                 self.find_interval_i(ai, ccid)
@@ -579,14 +582,34 @@ class bam_to_breakpoint_nanopore():
             seg_start = np.fromiter((v[1] for c in chroms for v in by.get(c, ())), dtype=np.int64, count=int(seg_off[-1]))
             seg_end = np.fromiter((v[2] for c in chroms for v in by.get(c, ())), dtype=np.int64, count=int(seg_off[-1]))
             self._search_ctx = PairSearch(self._chim, self._read_hashes(), self._e_key, self._e_row, seg_off, seg_start, seg_end)
+            # a few thousand chimeric reads: a step costs less than handing it to another thread
+            small = len(self._chim.read) < int(os.environ.get("CORAL_SEARCH_MIN_READS", "20000"))
+            n_threads = 0 if (_VERIFY_SET_ORDER or small) else int(os.environ.get("CORAL_SEARCH_THREADS", "6"))
+            floor = max(self.normal_cov * self.min_bp_cov_factor, 3.0)
+            self._search_ctx.set_params(self.min_cluster_cutoff, self.max_seq_len, self.max_breakpoint_distance_cutoff,
+                                        self.min_bp_match_cutoff_, floor, n_threads)
         return self._search_ctx
+
+    def _prefetch_step(self, idx):
+        """Tell the native search that interval ``idx`` will be searched: its step (a pure function of the coordinates) is
+        computed ahead on a worker thread while this thread does the order-dependent part of earlier steps."""
+        chrom, s, e = self.amplicon_intervals[idx][:3]
+        try:
+            si = self.pos2cni(chrom, s)[0]
+            ei = self.pos2cni(chrom, e)[0]
+        except Exception:
+            return
+        tid = self._tid_of[chrom]
+        if tid in self._seg_tids:
+            self._search().prefetch(tid, s, e, si, ei)
 
     def _search_step(self, chrom, s, e):
         """The part of one step of the interval search that is a pure function of the interval's coordinates (ibg:362-434):
         reachable segments and their read sets, the runs of neighbouring segments, the iteration order of every run's reads and
         the breakpoint candidates between each run and the interval — ONE native call (coral_search_step) that replays the
         reference's sets of read names on index arrays and filters the GPU-built pair table; then the clustering of every
-        run's candidates into exact breakpoints (coral_call_breakpoints).  Returns None (nothing reachable / interval off
+        run's candidates into exact breakpoints (coral_call_breakpoints, inside the same job).  The job is usually ready: it was
+        requested when the interval entered the queue (_prefetch_step).  Returns None (nothing reachable / interval off
         the CN segments) or (plan [(chr, first segment, last segment)], candidates per run, calls per run)."""
         try:
             si = self.pos2cni(chrom, s)[0]
@@ -596,13 +619,11 @@ class bam_to_breakpoint_nanopore():
         tid = self._tid_of[chrom]
         if tid not in self._seg_tids:
             raise KeyError(chrom)                       # self.chimeric_alignments_seg[chr] at ibg:371
-        groups, all_cands, orders = self._search().step(tid, s, e, si, ei, self.min_cluster_cutoff, self.max_seq_len,
-                                                        want_orders=_VERIFY_SET_ORDER)
+        groups, all_cands, orders, called = self._search().step(tid, s, e, si, ei, want_orders=_VERIFY_SET_ORDER)
         chroms = self.rec.header_chroms
         plan = [(chroms[int(g[0])], int(g[1]), int(g[2])) for g in groups]
         if _VERIFY_SET_ORDER:
             self._verify_step(tid, si, ei, plan, orders)
-        called = [self._cluster_and_call(c, False) for c in all_cands]
         return plan, all_cands, called
 
     def _verify_step(self, tid, si, ei, plan, orders):
@@ -802,6 +823,7 @@ class bam_to_breakpoint_nanopore():
                     for o in hit:
                         if o != cur and self.amplicon_intervals[o][3] < 0:
                             queue.append(o)
+                            self._prefetch_step(o)
                 else:
                     for part in parts:
                         nai = len(self.amplicon_intervals)
@@ -820,6 +842,7 @@ class bam_to_breakpoint_nanopore():
                                 else:
                                     conn[(cur, nai)].add(k)
                         queue.append(nai)
+                        self._prefetch_step(nai)
 
     def _add_clustered(self, cands: Candidates):
         """Tail shared by find_breakpoints and find_smalldel_breakpoints (ibg:691-718, ibg:775-802)."""

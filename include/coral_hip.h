@@ -176,10 +176,15 @@ int coral_bp_pair_table(int32_t n_reads, int32_t n_rows, const int32_t *off, con
  * segments)), per read hash(read name) and name id, the inverted index of hash_alignment_to_seg (e_key = contig << 32 |
  * segment, ascending; e_row = table row), the pair table (host copy of coral_bp_pair_table's output) and the CN segments
  * of every contig in file order (seg_off int64[n_tid + 1]; start, inclusive end).
- * coral_search_step(tid, s, e, si, ei, min_cluster_cutoff, max_seq_len): reach sets (ibg:369-384, replayed as CPython
- * sets: size and iteration order), segments with fewer reads than the cutoff dropped, runs of neighbouring segments
- * (ibg:392-419), and for every run alignment2bp of the united set's reads, in the set's iteration order, between the run
- * and (tid, s, e).  coral_search_within: alignment2bp_l of every read in table order.  coral_search_between: alignment2bp
+ * coral_search_params (once, before the first step): min_cluster_cutoff / max_seq_len (ibg:385-419), the arguments of
+ * coral_call_breakpoints (cluster distance, match cutoff, acceptance floor) and the number of look-ahead threads.
+ * coral_search_step(tid, s, e, si, ei): reach sets (ibg:369-384, replayed as CPython sets: size and iteration order),
+ * segments with fewer reads than the cutoff dropped, runs of neighbouring segments (ibg:392-419), for every run alignment2bp
+ * of the united set's reads, in the set's iteration order, between the run and (tid, s, e), and coral_call_breakpoints on
+ * every run's candidates (ibg:436-457; sub-cluster counter not advanced, Appendix A Q4) — coral_search_calls(group) returns
+ * that function's outputs.  A step is a pure function of its arguments: coral_search_prefetch asks for it to be computed
+ * ahead on a worker thread, coral_search_step then waits for / takes over / computes it; results do not depend on timing.
+ * coral_search_within: alignment2bp_l of every read in table order.  coral_search_between: alignment2bp
  * of the listed reads between two intervals.  coral_search_result then gives (valid until the next call on the handle)
  * groups int64[n_groups][4] = contig id, first segment, last segment, candidates of the run; cand int64[n_cand][13] =
  * c1, p1, o1, c2, p2, o2, read name id, i, j, query gap, swapped, mapq a, mapq b (the 11 fields of bu:81 / bu:294-295);
@@ -193,8 +198,13 @@ void *coral_search_create(int64_t n_reads, int64_t n_rows, const int64_t *off, c
                           const int64_t *seg_start, const int64_t *seg_end);
 int coral_search_free(void *handle);
 const char *coral_search_error(void *handle);
-int coral_search_step(void *handle, int64_t tid, int64_t s, int64_t e, int64_t si, int64_t ei, double min_cluster_cutoff,
-                      int64_t max_seq_len);
+int coral_search_params(void *handle, double min_cluster_cutoff, int64_t max_seq_len, int64_t bp_distance_cutoff,
+                        int64_t match_cutoff, double accept_floor, int32_t n_threads);
+int coral_search_prefetch(void *handle, int64_t tid, int64_t s, int64_t e, int64_t si, int64_t ei);
+int coral_search_step(void *handle, int64_t tid, int64_t s, int64_t e, int64_t si, int64_t ei);
+int coral_search_calls(void *handle, int64_t group, int32_t *n_clusters, const int32_t **cluster_size, int32_t *n_calls,
+                       const int64_t **head, const int64_t **p1, const int64_t **p2, const double **stats,
+                       const int32_t **flags, const int64_t **sup_off, const int64_t **sup_idx);
 int coral_search_within(void *handle, int32_t n_int, const int64_t *int_tid, const int64_t *int_start, const int64_t *int_end);
 int coral_search_between(void *handle, int64_t n_sel, const int32_t *reads, int64_t t1, int64_t s1, int64_t e1, int64_t t2,
                          int64_t s2, int64_t e2);

@@ -184,7 +184,11 @@ def test_gpu_matches_oracle_random_layouts(seed, tmp_path):
     rec = synth.generate(cfg, "cpu")
     cn = str(tmp_path / "cn.bed"); seeds = str(tmp_path / "seeds.bed")
     synth.write_cn_bed(cfg, cn); synth.write_seed_bed(cfg, seeds)
-    b = ibg.build_graph_from_records(DeviceRecords(rec, "cuda:0"), seeds, cn, str(tmp_path / "gpu"))
+    os.environ["CORAL_SEARCH_MIN_READS"] = "0"              # look-ahead threads of the interval search forced on
+    try:
+        b = ibg.build_graph_from_records(DeviceRecords(rec, "cuda:0"), seeds, cn, str(tmp_path / "gpu"))
+    finally:
+        del os.environ["CORAL_SEARCH_MIN_READS"]
     ob, ofiles = O.reconstruct_graph(HostRecords(rec), seeds, cn)
     assert len(b.lr_graph) == len(ob.lr_graph) and b.normal_cov == ob.normal_cov
     assert sorted(map(str, b.amplicon_intervals)) == sorted(map(str, ob.amplicon_intervals))

@@ -27,6 +27,18 @@ def test_strict_order_in_seeded_subprocess():
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
 
 
+@pytest.mark.skipif(HASHSEED0, reason="already running with PYTHONHASHSEED=0")
+def test_strict_order_with_lookahead_threads_in_seeded_subprocess():
+    """Same strict comparison with the look-ahead threads of the native interval search forced on (they are skipped for data
+    sets this small by default): steps computed ahead on worker threads must not change a single byte or order."""
+    env = dict(os.environ, PYTHONHASHSEED="0", CORAL_SEARCH_MIN_READS="0", CORAL_SEARCH_THREADS="3")
+    env.pop("CORAL_VERIFY_SET_ORDER", None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "test_host_logic_matches_reference"], env=env, capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+
+
 def test_result_holds_no_reference_cycles(monkeypatch, tmp_path):
     """The builder object must be freed by reference counting alone: a cyclic result would sit in memory (millions of
     read tuples at full size) until a full garbage collection finds it."""

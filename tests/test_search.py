@@ -114,7 +114,7 @@ def test_search_step_equals_single_queries(name, tmp_path, monkeypatch):
     for chrom, s, e, _ in b.amplicon_intervals:
         si, ei = b.pos2cni(chrom, s)[0], b.pos2cni(chrom, e)[0]
         tid = b._tid_of[chrom]
-        groups, cands, orders = S.step(tid, s, e, si, ei, b.min_cluster_cutoff, b.max_seq_len, want_orders=True)
+        groups, cands, orders, called = S.step(tid, s, e, si, ei, want_orders=True)
         chroms = b.rec.header_chroms
         b._verify_step(tid, si, ei, [(chroms[int(g[0])], int(g[1]), int(g[2])) for g in groups], orders)
         by = b.cns_intervals_by_chr
@@ -125,4 +125,11 @@ def test_search_step_equals_single_queries(name, tmp_path, monkeypatch):
             for f in c.FIELDS:
                 assert np.array_equal(getattr(c, f), getattr(want, f)), f
             n_cand += len(c)
+        # the calls made inside the step equal coral_call_breakpoints run on the run's candidates afterwards
+        for c, got in zip(cands, called):
+            want_sizes, want_calls = b._cluster_and_call(c, False)
+            assert list(got[0]) == list(want_sizes) and len(got[1]) == len(want_calls)
+            for x, y in zip(got[1], want_calls):
+                assert x[:3] == y[:3] and x[3].tolist() == y[3].tolist() and list(x[4]) == list(y[4])
+                assert [type(v) for v in x[4]] == [type(v) for v in y[4]]
     assert n_cand > 20
