@@ -56,9 +56,9 @@ def lib():
     L.coral_search_free.restype = C.c_int
     L.coral_search_error.argtypes = [C.c_void_p]
     L.coral_search_error.restype = C.c_char_p
-    L.coral_search_result.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.c_int64),
-                                      C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.POINTER(C.c_int64)),
-                                      C.POINTER(C.POINTER(C.c_int32))]
+    PI64, PF64, PI32 = C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.POINTER(C.c_int32))
+    L.coral_search_result.argtypes = [C.c_void_p, C.POINTER(C.c_int64), PI64, C.POINTER(C.c_int64), PI64, C.POINTER(C.c_int64), PI64,
+                                      PF64, PI64, PI32]
     L.coral_search_result.restype = C.c_int
     L.coral_search_step.argtypes = [C.c_void_p] + [C.c_int64] * 5
     L.coral_search_step.restype = C.c_int
@@ -66,11 +66,6 @@ def lib():
     L.coral_search_prefetch.restype = C.c_int
     L.coral_search_params.argtypes = [C.c_void_p, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_int32]
     L.coral_search_params.restype = C.c_int
-    L.coral_search_calls.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_int32)),
-                                     C.POINTER(C.c_int32)] + [C.POINTER(C.POINTER(C.c_int64))] * 3 + \
-        [C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int64)),
-         C.POINTER(C.POINTER(C.c_int64))]
-    L.coral_search_calls.restype = C.c_int
     L.coral_search_within.argtypes = [C.c_void_p, C.c_int32, P, P, P]
     L.coral_search_within.restype = C.c_int
     L.coral_search_between.argtypes = [C.c_void_p, C.c_int64, P] + [C.c_int64] * 6
@@ -96,6 +91,8 @@ def lib():
     L.coral_reach_create.restype = C.c_void_p
     L.coral_reach_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.coral_reach_keys.restype = C.c_int
+    L.coral_concordant_counts.argtypes = [C.c_int32, P, P, P, C.c_int64, C.c_int64, P, P, P]
+    L.coral_concordant_counts.restype = C.c_int
     L.coral_cluster_first_fit.argtypes = [C.c_int64, P, P, C.c_int64, P, C.POINTER(C.c_int32)]
     L.coral_cluster_first_fit.restype = C.c_int
     L.coral_bam_decode_open.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]

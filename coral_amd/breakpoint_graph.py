@@ -323,25 +323,51 @@ def cn_problem(g, normal_cov):
 
 
 def _independent_rows(A, tol=1e-9):
-    """Indices of a maximal linearly independent subset of the rows of A (entries are 0 / ±1): row k is kept when it is not
-    in the span of the rows kept before it (Gram-Schmidt against the orthonormal basis so far, applied twice for stability).
-    Redundant balance rows are consistent (right-hand side 0), so dropping them changes nothing."""
-    m, n = A.shape
-    Af = A.astype(np.float64)
-    norms = np.maximum(1.0, np.linalg.norm(Af, axis=1))
-    B = np.zeros((m, n))
-    keep = []
-    for k in range(m):
-        v = Af[k].copy()
-        if keep:
-            Q = B[:len(keep)]
-            v -= Q.T @ (Q @ v)
-            v -= Q.T @ (Q @ v)
-        nv = float(np.sqrt(v @ v))
-        if nv > tol * norms[k]:
-            B[len(keep)] = v / nv
-            keep.append(k)
-    return keep
+    """Indices (ascending) of a maximal linearly independent subset of the rows of A (entries are 0 / ±1), by QR with column
+    pivoting of Aᵀ.  Redundant balance rows are consistent (right-hand side 0), so which independent subset is kept changes
+    nothing: the kept rows span the same constraint space."""
+    from scipy.linalg import qr
+    m = A.shape[0]
+    if m == 0:
+        return []
+    r, piv = qr(A.T.astype(np.float64), mode="r", pivoting=True)
+    d = np.abs(np.diag(r)) if r.ndim == 2 else np.abs(r[:1])
+    rank = int(np.count_nonzero(d > tol * max(1.0, float(d[0])))) if len(d) else 0
+    return sorted(piv[:rank].tolist())
+
+
+def _newton_step(h, A, r, n, p):
+    """Solve [[diag(h), Aᵀ], [A, 0]] [dx; dnu] = -r by eliminating the variables with h > 0 (dx_i = -(r_i + (Aᵀdnu)_i) / h_i):
+    what remains is a system in dnu and the few variables with h == 0 (concordant edges without read support), less than
+    half the size of the KKT matrix.  Returns None when that system is singular."""
+    pos = h > 0
+    zero = np.nonzero(~pos)[0]
+    rd, rp = r[:n], r[n:]
+    Ap = A[:, pos]
+    hinv = 1.0 / h[pos]
+    S = (Ap * hinv) @ Ap.T
+    nz = len(zero)
+    if nz:
+        Az = A[:, zero]
+        M = np.zeros((p + nz, p + nz))
+        M[:p, :p] = S
+        M[:p, p:] = -Az
+        M[p:, :p] = Az.T
+        rhs = np.concatenate([rp - Ap @ (hinv * rd[pos]), -rd[zero]])
+    else:
+        M, rhs = S, rp - Ap @ (hinv * rd[pos])
+    try:
+        sol = np.linalg.solve(M, rhs)
+    except np.linalg.LinAlgError:
+        return None
+    if not np.all(np.isfinite(sol)):
+        return None
+    dnu = sol[:p]
+    dx = np.empty(n)
+    dx[pos] = -(rd[pos] + Ap.T @ dnu) * hinv
+    if nz:
+        dx[zero] = sol[p:]
+    return np.concatenate([dx, dnu])
 
 
 def solve_cn_lr(w_inv, w_lin, w_log, A, max_iter=200):
@@ -359,21 +385,25 @@ def solve_cn_lr(w_inv, w_lin, w_log, A, max_iter=200):
     p = A.shape[0]
     x = np.ones(n)
     nu = np.zeros(p)
-    K = np.zeros((n + p, n + p))
-    K[:n, n:] = A.T
-    K[n:, :n] = A
-    diag = np.arange(n)
+    K = None                                     # full KKT matrix, built only if the reduced solve below is not applicable
 
     def kkt_residual(x, nu):
         return np.concatenate([w_lin - w_log / x - w_inv / (x * x) + A.T @ nu, A @ x])
 
     r = kkt_residual(x, nu)
     for _ in range(max_iter):
-        K[diag, diag] = w_log / (x * x) + 2.0 * w_inv / (x * x * x)
-        try:
-            step = np.linalg.solve(K, -r)
-        except np.linalg.LinAlgError:
-            step = np.linalg.lstsq(K, -r, rcond=None)[0]
+        h = w_log / (x * x) + 2.0 * w_inv / (x * x * x)
+        step = _newton_step(h, A, r, n, p)
+        if step is None:                         # (not seen in practice) the reduced system is singular: full KKT matrix
+            if K is None:
+                K = np.zeros((n + p, n + p))
+                K[:n, n:] = A.T
+                K[n:, :n] = A
+            K[np.arange(n), np.arange(n)] = h
+            try:
+                step = np.linalg.solve(K, -r)
+            except np.linalg.LinAlgError:
+                step = np.linalg.lstsq(K, -r, rcond=None)[0]
         dx, dnu = step[:n], step[n:]
         t = 1.0
         shrink = dx < 0
@@ -419,12 +449,26 @@ def solve_cn_lr(w_inv, w_lin, w_log, A, max_iter=200):
 solve_cn_lr.last_residual = 0.0
 
 
+_blas = None
+
+
+def _single_threaded_blas():
+    """The CN systems are ~100 x 100: BLAS worker threads only add hand-off latency there (and, next to another OpenMP pool
+    in the process, two orders of magnitude of spinning).  One controller per process; entering the limit is cheap."""
+    global _blas
+    if _blas is None:
+        from threadpoolctl import ThreadpoolController
+        _blas = ThreadpoolController()
+    return _blas.limit(limits=1, user_api="blas")
+
+
 def compute_cn_lr(g, normal_cov_lr):
     """Fill the CN field of every edge of ``g`` and ``g.max_cn`` (bg:495-606)."""
     ls, lc, ld = len(g.sequence_edges), len(g.concordant_edges), len(g.discordant_edges)
     w_inv, w_lin, w_log, A = cn_problem(g, normal_cov_lr)
     if A.shape[0] > 0:
-        x = solve_cn_lr(w_inv, w_lin, w_log, A)
+        with _single_threaded_blas():
+            x = solve_cn_lr(w_inv, w_lin, w_log, A)
         doubled = [float(v) * 2 for v in x]
         for k in range(ls):
             g.sequence_edges[k][-1] = doubled[k]

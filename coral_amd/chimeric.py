@@ -36,6 +36,7 @@ class ChimericTable:
         self.read_length = np.zeros(0, np.int64)      # per name id, -1 = no primary seen
         self.pairs = np.zeros((0, 8), np.int32)       # coral_bp_pair_table: two slots per row (see csrc/coral_kernels.hip, K4)
         self.dev_rows = None                          # coral_sa_table's rows as they stay in HBM (int32 [n_rows, 8])
+        self.staging = None                           # owner of the pinned host buffers the arrays above are views of
         self.n_mapq60_plain = 0
 
     @property
@@ -61,7 +62,7 @@ def build_chimeric_table(dr) -> ChimericTable:
         raise ZeroDivisionError("division by zero")
     _lib.check(rc, "coral_nm_stats")
     T.n_mapq60_plain, T.nm_sum, T.nm_sum_sq = int(cnt.value), float(s0.value), float(s1.value)
-    cols, off, name_id, failed, rl, T.pairs, T.dev_rows = kernels.sa_table(dr)
+    cols, off, name_id, failed, rl, T.pairs, T.dev_rows, T.staging = kernels.sa_table(dr)
     T.read_length = rl
     T.name_id, T.failed, T.off = name_id, failed, off
     T.qs, T.qe, T.tid, T.ra, T.rb, T.strand, T.mapq = (cols[k] for k in range(7))
@@ -124,12 +125,14 @@ class PairSearch:
         from . import _lib
         self._C, self._lib, self._L = C, _lib, _lib.lib()
         i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+        if T.staging is not None:
+            T.staging.wait("pairs")                   # the pair table's device -> host copy ran beside the CIGAR scan
         # the handle borrows these arrays: keep them alive (and unchanged in place) for its lifetime
-        self._keep = [i64(T.off), i64(T.read), i64(T.tid), i64(T.ra), i64(T.rb), T.cni0, T.cni1, i64(read_hash), i64(T.name_id),
+        self._keep = [T, i64(T.off), i64(T.read), i64(T.tid), i64(T.ra), i64(T.rb), T.cni0, T.cni1, i64(read_hash), i64(T.name_id),
                       i64(e_key), i64(e_row), np.ascontiguousarray(T.pairs, dtype=np.int32), i64(seg_off), i64(seg_start), i64(seg_end)]
         assert T.cni0.dtype == np.int64 and T.cni1.dtype == np.int64 and T.cni0.flags.c_contiguous and T.cni1.flags.c_contiguous
-        assert self._keep[11].shape == (2 * T.n_rows, 8), "pair table must hold two slots per table row"
-        k = self._keep
+        k = self._keep[1:]
+        assert k[11].shape == (2 * T.n_rows, 8), "pair table must hold two slots per table row"
         ptr = lambda a: a.ctypes.data
         self._h = self._L.coral_search_create(T.n_reads, T.n_rows, ptr(k[0]), ptr(k[1]), ptr(k[2]), ptr(k[3]), ptr(k[4]), ptr(k[5]),
                                               ptr(k[6]), ptr(k[7]), ptr(k[8]), len(k[9]), ptr(k[9]), ptr(k[10]), ptr(k[11]),
@@ -154,25 +157,49 @@ class PairSearch:
             raise self._lib.CoralHipError("%s failed (%d): %s" % (what, rc, msg))
 
     def _result(self, want_orders=False):
+        """(groups int64 [G, 4], [Candidates per run], [read order per run] | None, [(cluster sizes, calls) per run]) of the last
+        native call; calls = [(head, p1, p2, support index array, stats list)] as bpcluster.call_breakpoints returns them."""
         C = self._C
-        ng, nc = C.c_int64(0), C.c_int64(0)
-        gp, cp, oo, op = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.POINTER(C.c_int32)()
-        self._lib.check(self._L.coral_search_result(self._h, C.byref(ng), C.byref(gp), C.byref(nc), C.byref(cp), C.byref(oo),
-                                                    C.byref(op)), "coral_search_result")
-        groups = np.ctypeslib.as_array(gp, shape=(ng.value, 4)).copy() if ng.value else np.zeros((0, 4), dtype=np.int64)
+        nm, nc, ns = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        mp, cp, sp, oo = (C.POINTER(C.c_int64)() for _ in range(4))
+        stp, op = C.POINTER(C.c_double)(), C.POINTER(C.c_int32)()
+        self._lib.check(self._L.coral_search_result(self._h, C.byref(nm), C.byref(mp), C.byref(nc), C.byref(cp), C.byref(ns),
+                                                    C.byref(sp), C.byref(stp), C.byref(oo), C.byref(op)), "coral_search_result")
+        meta = mp[:nm.value]
+        ng = meta[0]
         rows = np.ctypeslib.as_array(cp, shape=(nc.value, 13)).copy() if nc.value else np.zeros((0, 13), dtype=np.int64)
-        out, at = [], 0
-        for g in range(ng.value):
-            n = int(groups[g, 3])
+        sup = np.ctypeslib.as_array(sp, shape=(ns.value,)).copy() if ns.value else np.zeros(0, dtype=np.int64)
+        groups, cands, called = np.zeros((ng, 4), dtype=np.int64), [], []
+        at, m, n_calls_seen = 0, 1, 0
+        for g in range(ng):
+            t, b0, b1, n, ncl, ncall = meta[m:m + 6]
+            groups[g] = (t, b0, b1, n)
             part = rows[at:at + n]
-            out.append(Candidates(**{k: part[:, j] for j, k in enumerate(Candidates.FIELDS)}))
             at += n
+            cands.append(Candidates(**{k: part[:, j] for j, k in enumerate(Candidates.FIELDS)}))
+            m += 6
+            sizes = meta[m:m + ncl]
+            m += ncl
+            calls = []
+            if ncall:
+                stats = stp[6 * n_calls_seen:6 * (n_calls_seen + ncall)]
+                for k in range(ncall):
+                    head, p1, p2, flags, s0, s1 = meta[m:m + 6]
+                    m += 6
+                    st = stats[6 * k:6 * k + 6]
+                    if flags & 1:
+                        st[2] = 0                             # the reference's ValueError branch stores the integer 0
+                    if flags & 2:
+                        st[3] = 0
+                    calls.append((head, p1, p2, sup[s0:s1], st))
+                n_calls_seen += ncall
+            called.append((sizes, calls))
         orders = [] if want_orders else None
-        if want_orders and ng.value:
-            off = np.ctypeslib.as_array(oo, shape=(ng.value + 1,)).copy()
-            flat = np.ctypeslib.as_array(op, shape=(int(off[-1]),)).copy() if off[-1] else np.zeros(0, dtype=np.int32)
-            orders = [flat[off[g]:off[g + 1]].astype(np.int64) for g in range(ng.value)]
-        return groups, out, orders
+        if want_orders and ng:
+            off = oo[:ng + 1]
+            flat = np.ctypeslib.as_array(op, shape=(off[-1],)).copy() if off[-1] else np.zeros(0, dtype=np.int32)
+            orders = [flat[off[g]:off[g + 1]].astype(np.int64) for g in range(ng)]
+        return groups, cands, orders, called
 
     def set_params(self, min_cluster_cutoff, max_seq_len, bp_distance_cutoff, match_cutoff, accept_floor, n_threads):
         """Parameters of the build (ibg:385-391, :436-457) and the number of look-ahead threads; once, before the first step."""
@@ -183,36 +210,12 @@ class PairSearch:
         """Have the step of interval (tid, s, e) on segments si..ei computed ahead on a worker thread (pure function)."""
         self._lib.check(self._L.coral_search_prefetch(self._h, int(tid), int(s), int(e), int(si), int(ei)), "coral_search_prefetch")
 
-    def _calls(self, g):
-        """(cluster sizes, [(head, p1, p2, support index array, stats list)]) of run ``g`` — coral_call_breakpoints' result."""
-        C = self._C
-        ncl, nc = C.c_int32(0), C.c_int32(0)
-        csz, fl = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
-        hd, p1, p2, so, si_ = (C.POINTER(C.c_int64)() for _ in range(5))
-        st = C.POINTER(C.c_double)()
-        self._lib.check(self._L.coral_search_calls(self._h, g, C.byref(ncl), C.byref(csz), C.byref(nc), C.byref(hd), C.byref(p1),
-                                                   C.byref(p2), C.byref(st), C.byref(fl), C.byref(so), C.byref(si_)), "coral_search_calls")
-        sizes = csz[:ncl.value]
-        calls = []
-        if nc.value:
-            off = so[:nc.value + 1]
-            sup_all = np.ctypeslib.as_array(si_, shape=(off[-1],)).copy() if off[-1] else np.zeros(0, dtype=np.int64)
-            for k in range(nc.value):
-                stats = st[6 * k:6 * k + 6]
-                if fl[k] & 1:
-                    stats[2] = 0                              # the reference's ValueError branch stores the integer 0
-                if fl[k] & 2:
-                    stats[3] = 0
-                calls.append((hd[k], p1[k], p2[k], sup_all[off[k]:off[k + 1]], stats))
-        return sizes, calls
-
     def step(self, tid, s, e, si, ei, want_orders=False):
         """One step of the interval search for interval (tid, s, e) lying on segments si..ei: (groups int64 [G, 4] =
         contig id, first segment, last segment, candidates; [Candidates per group]; [read order per group] or None;
         [coral_call_breakpoints result per group])."""
         self._check(self._L.coral_search_step(self._h, int(tid), int(s), int(e), int(si), int(ei)), "coral_search_step")
-        groups, cands, orders = self._result(want_orders)
-        return groups, cands, orders, [self._calls(g) if len(cands[g]) else ([], []) for g in range(len(cands))]
+        return self._result(want_orders)
 
     def within(self, intervals) -> Candidates:
         """alignment2bp_l (bu:129-186) of every chimeric read, dict order, against [(tid, start, end)]."""

@@ -268,3 +268,47 @@ extern "C" int coral_nm_stats(int64_t n, const int32_t *tid, const int64_t *sa_o
     *sum_e2 = s1;
     return CORAL_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Read support of the concordant edges (ibg:1043-1055).  For edge q the reference fetches the reads covering four positions
+// (p, p + 1, p - 101, p + 101), intersects the four NAME sets and removes the names that support a discordant edge at either
+// node.  Here the four fetches arrive as record ordinals (coral_point_cover), names are ids, and a per-name stamp replaces
+// the sets: bit d of mark[name] = "covers position d of the current edge".
+extern "C" int coral_concordant_counts(int32_t n_edges, const int64_t *pt_off, const int64_t *pt_rec, const int32_t *rec_name,
+                                       int64_t n_rec, int64_t n_names, const int64_t *sup_off, const int64_t *sup_name,
+                                       int64_t *count) {
+    if (n_edges < 0 || n_names < 0 || !count || (n_edges > 0 && (!pt_off || !sup_off))) return CORAL_ERR_ARG;
+    if (n_edges == 0) return CORAL_OK;
+    if ((pt_off[4 * (size_t)n_edges] > 0 && (!pt_rec || !rec_name)) || (sup_off[n_edges] > 0 && !sup_name)) return CORAL_ERR_ARG;
+    std::vector<uint32_t> mark((size_t)n_names, 0u);          // (edge + 1) << 6 | bits
+    for (int32_t q = 0; q < n_edges; ++q) {
+        const uint32_t tag = ((uint32_t)q + 1u) << 6;
+        for (int d = 0; d < 4; ++d)
+            for (int64_t k = pt_off[4 * q + d]; k < pt_off[4 * q + d + 1]; ++k) {
+                const int64_t rec = pt_rec[k];
+                if (rec < 0 || rec >= n_rec) return CORAL_ERR_ARG;
+                const int32_t nm = rec_name[rec];
+                if (nm < 0 || nm >= n_names) return CORAL_ERR_ARG;
+                uint32_t &m = mark[(size_t)nm];
+                if ((m & ~63u) != tag) m = tag;
+                m |= 1u << d;
+            }
+        for (int64_t k = sup_off[q]; k < sup_off[q + 1]; ++k) {
+            const int64_t nm = sup_name[k];
+            if (nm < 0 || nm >= n_names) return CORAL_ERR_ARG;
+            uint32_t &m = mark[(size_t)nm];
+            if ((m & ~63u) != tag) m = tag;
+            m |= 16u;                                          // supports a discordant edge at one of the two nodes
+        }
+        int64_t c = 0;
+        for (int64_t k = pt_off[4 * q]; k < pt_off[4 * q + 1]; ++k) {
+            uint32_t &m = mark[(size_t)rec_name[pt_rec[k]]];
+            if ((m & 63u) == 15u) {                            // all four positions, no discordant support, not counted yet
+                ++c;
+                m |= 32u;
+            }
+        }
+        count[q] = c;
+    }
+    return CORAL_OK;
+}

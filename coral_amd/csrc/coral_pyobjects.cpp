@@ -89,9 +89,46 @@ PyObject *read_tuples(PyObject *, PyObject *args) {
     return out;
 }
 
+// count_distinct3(a, b, c) -> number of distinct (a[k], b[k], c[k]) triples  (= len(set(zip(a, b, c))))
+PyObject *count_distinct3(PyObject *, PyObject *args) {
+    PyObject *a_o, *b_o, *c_o;
+    if (!PyArg_ParseTuple(args, "OOO", &a_o, &b_o, &c_o)) return nullptr;
+    I64View a, b, c;
+    if (!a.get(a_o, "a") || !b.get(b_o, "b") || !c.get(c_o, "c")) return nullptr;
+    if (b.n != a.n || c.n != a.n) {
+        PyErr_SetString(PyExc_ValueError, "the three arrays must have the same length");
+        return nullptr;
+    }
+    size_t cap = 16;
+    while (cap < (size_t)a.n * 2) cap <<= 1;
+    int64_t *slot = static_cast<int64_t *>(PyMem_Malloc(cap * sizeof(int64_t)));      // index of the triple stored there, -1 = empty
+    if (!slot) return PyErr_NoMemory();
+    for (size_t k = 0; k < cap; ++k) slot[k] = -1;
+    Py_ssize_t distinct = 0;
+    for (Py_ssize_t k = 0; k < a.n; ++k) {
+        uint64_t h = (uint64_t)a.p[k] * 0x9E3779B97F4A7C15ull;
+        h ^= ((uint64_t)b.p[k] + 0x7F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+        h ^= ((uint64_t)c.p[k] + 0x94D049BBull) * 0x94D049BB133111EBull;
+        size_t at = (size_t)(h ^ (h >> 29)) & (cap - 1);
+        for (;;) {
+            const int64_t j = slot[at];
+            if (j < 0) {
+                slot[at] = k;
+                ++distinct;
+                break;
+            }
+            if (a.p[j] == a.p[k] && b.p[j] == b.p[k] && c.p[j] == c.p[k]) break;
+            at = (at + 1) & (cap - 1);
+        }
+    }
+    PyMem_Free(slot);
+    return PyLong_FromSsize_t(distinct);
+}
+
 PyMethodDef methods[] = {
     {"names_of", names_of, METH_VARARGS, "names_of(names, ids) -> [names[k] for k in ids]  (ids: contiguous int64 array)"},
     {"read_tuples", read_tuples, METH_VARARGS, "read_tuples(names, ids, i, j) -> [(names[ids[k]], i[k], j[k]), ...]"},
+    {"count_distinct3", count_distinct3, METH_VARARGS, "count_distinct3(a, b, c) -> len(set(zip(a, b, c)))  (contiguous int64 arrays)"},
     {nullptr, nullptr, 0, nullptr}};
 
 PyModuleDef module = {PyModuleDef_HEAD_INIT, "_pyobjects", "Python containers of the graph build, built with the C API.", -1, methods,

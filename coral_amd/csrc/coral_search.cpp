@@ -61,9 +61,33 @@ struct StepResult {
     std::vector<int32_t> order;                           // reads (table index) of every run in set-iteration order
     std::vector<int64_t> order_off;                       // [n_groups + 1]
     std::vector<Calls> calls;                             // per run
+    // the same, flattened for one-shot retrieval (coral_search_result): see the header for the layout of `meta`
+    std::vector<int64_t> meta, sup;
+    std::vector<double> stats;
     void clear() {
         rc = CORAL_OK; err[0] = 0;
         groups.clear(); cand.clear(); order.clear(); order_off.assign(1, 0); calls.clear();
+        meta.assign(1, 0); sup.clear(); stats.clear();
+    }
+    void flatten() {
+        const size_t ng = groups.size() / 4;
+        meta.assign(1, (int64_t)ng);
+        sup.clear(); stats.clear();
+        for (size_t g = 0; g < ng; ++g) {
+            static const Calls none;
+            const Calls &c = g < calls.size() ? calls[g] : none;
+            meta.insert(meta.end(), groups.begin() + 4 * g, groups.begin() + 4 * g + 4);
+            meta.push_back(c.n_clusters);
+            meta.push_back(c.n_calls);
+            for (int32_t k = 0; k < c.n_clusters; ++k) meta.push_back(c.cluster_size[(size_t)k]);
+            for (int32_t k = 0; k < c.n_calls; ++k) {
+                const int64_t row[6] = {c.head[(size_t)k], c.p1[(size_t)k], c.p2[(size_t)k], c.flags[(size_t)k],
+                                        (int64_t)sup.size(), (int64_t)sup.size() + (c.sup_off[(size_t)k + 1] - c.sup_off[(size_t)k])};
+                meta.insert(meta.end(), row, row + 6);
+                sup.insert(sup.end(), c.sup_idx.begin() + c.sup_off[(size_t)k], c.sup_idx.begin() + c.sup_off[(size_t)k + 1]);
+                stats.insert(stats.end(), c.stats.begin() + 6 * (size_t)k, c.stats.begin() + 6 * (size_t)k + 6);
+            }
+        }
     }
 };
 
@@ -317,6 +341,7 @@ void compute_step(Search &S, Scratch &T, const int64_t key[5], StepResult &R) {
             at += n_c;
         }
     }
+    R.flatten();
     if (S.profile) {
         const double t3 = now_s();
         std::lock_guard<std::mutex> lk(S.pm);
@@ -474,31 +499,20 @@ extern "C" int coral_search_step(void *h, int64_t tid, int64_t s, int64_t e, int
 }
 
 // Arrays of the last result (owned by the handle, valid until the next step / within / between call on it).
-extern "C" int coral_search_result(void *h, int64_t *n_groups, const int64_t **groups, int64_t *n_cand, const int64_t **cand,
-                                   const int64_t **order_off, const int32_t **order) {
-    if (!h || !n_groups || !groups || !n_cand || !cand) return CORAL_ERR_ARG;
+extern "C" int coral_search_result(void *h, int64_t *n_meta, const int64_t **meta, int64_t *n_cand, const int64_t **cand,
+                                   int64_t *n_sup, const int64_t **sup, const double **stats, const int64_t **order_off,
+                                   const int32_t **order) {
+    if (!h || !n_meta || !meta || !n_cand || !cand || !n_sup || !sup || !stats) return CORAL_ERR_ARG;
     const StepResult &R = *((Search *)h)->current;
-    *n_groups = (int64_t)R.groups.size() / 4;
-    *groups = R.groups.data();
+    *n_meta = (int64_t)R.meta.size();
+    *meta = R.meta.data();
     *n_cand = (int64_t)R.cand.size() / 13;
     *cand = R.cand.data();
+    *n_sup = (int64_t)R.sup.size();
+    *sup = R.sup.data();
+    *stats = R.stats.data();
     if (order_off) *order_off = R.order_off.data();
     if (order) *order = R.order.data();
-    return CORAL_OK;
-}
-
-// coral_call_breakpoints' outputs for run `g` of the last coral_search_step (same meaning as that function's arguments).
-extern "C" int coral_search_calls(void *h, int64_t g, int32_t *n_clusters, const int32_t **cluster_size, int32_t *n_calls,
-                                  const int64_t **head, const int64_t **p1, const int64_t **p2, const double **stats,
-                                  const int32_t **flags, const int64_t **sup_off, const int64_t **sup_idx) {
-    if (!h || !n_clusters || !cluster_size || !n_calls || !head || !p1 || !p2 || !stats || !flags || !sup_off || !sup_idx)
-        return CORAL_ERR_ARG;
-    const StepResult &R = *((Search *)h)->current;
-    if (g < 0 || (size_t)g >= R.calls.size()) return CORAL_ERR_ARG;
-    const Calls &c = R.calls[(size_t)g];
-    *n_clusters = c.n_clusters; *cluster_size = c.cluster_size.data(); *n_calls = c.n_calls;
-    *head = c.head.data(); *p1 = c.p1.data(); *p2 = c.p2.data(); *stats = c.stats.data(); *flags = c.flags.data();
-    *sup_off = c.sup_off.data(); *sup_idx = c.sup_idx.data();
     return CORAL_OK;
 }
 
@@ -550,6 +564,7 @@ extern "C" int coral_search_within(void *h, int32_t n_int, const int64_t *int_ti
     const int64_t g[4] = {-1, -1, -1, (int64_t)(R.cand.size() / 13)};
     R.groups.insert(R.groups.end(), g, g + 4);
     R.order_off.push_back(0);
+    R.flatten();
     if (!contigs_ok) { snprintf(S.err, sizeof(S.err), "search_within: contig outside chr1..22,X,Y,M"); return CORAL_ERR_FORMAT; }
     return CORAL_OK;
 }
@@ -573,6 +588,7 @@ extern "C" int coral_search_between(void *h, int64_t n_sel, const int32_t *reads
     const int64_t g[4] = {t1, -1, -1, (int64_t)(R.cand.size() / 13)};
     R.groups.insert(R.groups.end(), g, g + 4);
     R.order_off.push_back(0);
+    R.flatten();
     if (!contigs_ok) { snprintf(S.err, sizeof(S.err), "search_between: contig outside chr1..22,X,Y,M"); return CORAL_ERR_FORMAT; }
     return CORAL_OK;
 }

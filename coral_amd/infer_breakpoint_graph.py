@@ -83,15 +83,33 @@ def interval_exclusive(a, lst):
 
 
 class _ChimericAlignments(dict):
-    """``name -> (qint, rint(+cniset), qual, nm)`` exactly as the reference stores it, materialised from the
-    ChimericTable the first time an entry is read (keys exist from the start, in the reference's order)."""
+    """``name -> (qint, rint(+cniset), qual, nm)`` exactly as the reference stores it (cp:269, ibg:200-210), over the
+    ChimericTable: the keys (read names, in the reference's insertion order) are created the first time anything but the
+    SIZE is asked for, a value the first time that entry is read.  Every access path of ``dict`` is overridden — including
+    ``__iter__``, so that ``dict(x)`` / ``x.copy()`` / ``{**x}`` take the generic route through ``keys()`` and
+    ``__getitem__`` instead of copying the raw table."""
 
-    def __init__(self, owner, names_in_order):
-        super().__init__(dict.fromkeys(names_in_order))
+    def __init__(self, owner, name_ids):
+        super().__init__()
         self._owner = weakref.proxy(owner)      # no reference cycle: the result is freed by reference counting, not by the GC
-        self._names = names_in_order
+        self._name_ids = name_ids
+        self._names_ = None                     # read names in dict order
         self._index_ = None
-        self._made = []                      # keys holding a materialised value
+        self._filled = False
+        self._n = len(name_ids)
+        self._made = []                         # keys holding a materialised value
+
+    # -- lazy parts ---------------------------------------------------------------------------------
+    @property
+    def _names(self):
+        if self._names_ is None:
+            self._names_ = self._owner._names_of(self._name_ids)
+        return self._names_
+
+    def _fill(self):
+        if not self._filled:
+            self._filled = True
+            dict.update(self, dict.fromkeys(self._names))
 
     @property
     def _index(self):
@@ -118,7 +136,24 @@ class _ChimericAlignments(dict):
         nm = [float(T.nm[k]) for k in range(a, b)]
         return (qint, rint, qual, nm)
 
+    # -- dict protocol --------------------------------------------------------------------------------
+    def __len__(self):
+        return dict.__len__(self) if self._filled else self._n
+
+    def __contains__(self, key):
+        self._fill()
+        return dict.__contains__(self, key)
+
+    def __iter__(self):
+        self._fill()
+        return dict.__iter__(self)
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
     def __getitem__(self, key):
+        self._fill()
         v = dict.__getitem__(self, key)
         if v is None:
             v = self._make(key)
@@ -130,13 +165,54 @@ class _ChimericAlignments(dict):
         return self[key] if key in self else default
 
     def items(self):
-        return [(k, self[k]) for k in dict.keys(self)]
+        return [(k, self[k]) for k in self.keys()]
 
     def values(self):
-        return [self[k] for k in dict.keys(self)]
+        return [self[k] for k in self.keys()]
+
+    def __setitem__(self, key, value):
+        self._fill()
+        dict.__setitem__(self, key, value)
 
     def __delitem__(self, key):
+        self._fill()
         dict.__delitem__(self, key)
+
+    def pop(self, key, *default):
+        self._fill()
+        if dict.__contains__(self, key):
+            v = self[key]
+            dict.__delitem__(self, key)
+            return v
+        if default:
+            return default[0]
+        raise KeyError(key)
+
+    def setdefault(self, key, default=None):
+        if key not in self:
+            self[key] = default
+        return self[key]
+
+    def update(self, *a, **kw):
+        self._fill()
+        dict.update(self, *a, **kw)
+
+    def copy(self):
+        return dict(self.items())
+
+    def __eq__(self, other):
+        return dict(self.items()) == other
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        return repr(dict(self.items()))
+
+    def __reduce__(self):
+        return (dict, (self.items(),))
 
     def invalidate(self):
         for k in self._made:
@@ -342,8 +418,7 @@ class bam_to_breakpoint_nanopore():
         names = self.rec.names
         has = np.nonzero(T.read_length >= 0)[0]
         self.read_length = _LazyReadLength(names, T.read_length, has)
-        self._chim_names = self._names_of(T.name_id)
-        self.chimeric_alignments = _ChimericAlignments(self, self._chim_names)
+        self.chimeric_alignments = _ChimericAlignments(self, T.name_id)
         logging.info(_t() + "Fetched %d chimeric reads." % (len(self.chimeric_alignments)))
         logging.info(_t() + "Computed alignment intervals on all chimeric reads.")
 
@@ -630,7 +705,7 @@ class bam_to_breakpoint_nanopore():
         """Tests only (CORAL_VERIFY_SET_ORDER=1): ibg:369-419 with REAL sets of str; the native step must give the same runs
         and, for every run, the same iteration order of the united set."""
         T = self._chim
-        names, chroms, by = self._chim_names, self.rec.header_chroms, self.cns_intervals_by_chr
+        names, chroms, by = self.chimeric_alignments._names, self.rec.header_chroms, self.cns_intervals_by_chr
         lo = np.searchsorted(self._e_key, tid * (1 << 32) + si, side="left")
         hi = np.searchsorted(self._e_key, tid * (1 << 32) + ei + 1, side="left")
         real: Dict[str, Dict[int, set]] = {}
@@ -993,29 +1068,42 @@ class bam_to_breakpoint_nanopore():
             t1, t2 = self._tid_of[e[0]], self._tid_of[e[3]]
             pts += [(t1, e[1]), (t2, e[4]), (t1, e[1] - cut - 1), (t2, e[4] + cut)]
         cover = kernels.point_cover(self.rec, pts) if pts else []
+        if not edges:
+            return
         nid = self.rec.h_name_id
         names = self.rec.names
-        n_names = self.rec.n_names
-        is_bp_read = np.zeros(n_names, dtype=bool)                  # scratch: reads supporting a discordant edge at either node
+        # one native pass over all edges (coral_concordant_counts): the four fetches of an edge as record ordinals, the reads
+        # of the discordant edges at its two nodes as name ids
+        pt_off = np.zeros(4 * len(edges) + 1, dtype=np.int64)
+        np.cumsum([len(c) for c in cover], out=pt_off[1:])
+        pt_rec = np.ascontiguousarray(np.concatenate(cover), dtype=np.int64) if pt_off[-1] else np.zeros(0, dtype=np.int64)
+        sup_parts, sup_off, by_name = [], [0], {}
         for q, (g, e) in enumerate(edges):
-            left, right = nid[cover[4 * q]], nid[cover[4 * q + 1]]    # fetch order (record ordinals ascending)
-            rls, rrs, rls1, rrs1 = np.unique(left), np.unique(right), np.unique(nid[cover[4 * q + 2]]), np.unique(nid[cover[4 * q + 3]])
-            both = np.intersect1d(np.intersect1d(rls, rrs, assume_unique=True),
-                                  np.intersect1d(rls1, rrs1, assume_unique=True), assume_unique=True)
-            e[9] = ReadNameSet(names, left, right)                    # rls | rrs (ibg:1054) — name strings only on demand
-            support = [g.discordant_edges[k][10] for node in ((e[0], e[1], e[2]), (e[3], e[4], e[5])) for k in g.nodes[node][2]]
-            if not support:
-                e[8] = int(len(both))
-                continue
-            id_arrays = [s_.name_ids() if isinstance(s_, ReadSupportSet) else None for s_ in support]
-            if all(a is not None for a in id_arrays):                 # the usual case: every support set is still arrays
-                marked = np.concatenate(id_arrays)
-                is_bp_read[marked] = True
-                e[8] = int(len(both) - np.count_nonzero(is_bp_read[both]))
-                is_bp_read[marked] = False
-            else:                                                     # somebody materialised / replaced a support set: by name
-                rbps = {t[0] for s_ in support for t in s_}
-                e[8] = sum(1 for nm in self._names_of(both) if nm not in rbps)
+            e[9] = ReadNameSet(names, nid, cover[4 * q], cover[4 * q + 1])      # rls | rrs (ibg:1054) — name strings only on demand
+            n_here = 0
+            for node in ((e[0], e[1], e[2]), (e[3], e[4], e[5])):
+                for k in g.nodes[node][2]:
+                    s_ = g.discordant_edges[k][10]
+                    ids = s_.name_ids() if isinstance(s_, ReadSupportSet) else None
+                    if ids is None:                                     # somebody materialised / replaced a support set: by name
+                        by_name.setdefault(q, set()).update(t[0] for t in s_)
+                    else:
+                        sup_parts.append(ids)
+                        n_here += len(ids)
+            sup_off.append(sup_off[-1] + n_here)
+        sup = np.ascontiguousarray(np.concatenate(sup_parts), dtype=np.int64) if sup_parts else np.zeros(0, dtype=np.int64)
+        sup_off = np.asarray(sup_off, dtype=np.int64)
+        count = np.zeros(len(edges), dtype=np.int64)
+        nid32 = np.ascontiguousarray(nid, dtype=np.int32)
+        _lib.check(_lib.lib().coral_concordant_counts(len(edges), pt_off.ctypes.data, pt_rec.ctypes.data, nid32.ctypes.data, len(nid32),
+                                                      self.rec.n_names, sup_off.ctypes.data, sup.ctypes.data, count.ctypes.data),
+                   "coral_concordant_counts")
+        for q, (g, e) in enumerate(edges):
+            e[8] = int(count[q])
+            if q in by_name:                                            # rare: redo this edge with the names themselves
+                sets = [set(self._names_of(np.unique(nid[cover[4 * q + d]]))) for d in range(4)]
+                e[8] = len((sets[0] & sets[1] & sets[2] & sets[3]) - by_name[q] -
+                           {names[i] for i in sup[sup_off[q]:sup_off[q + 1]].tolist()})
 
     # ---- SURVEY.md §8(f) item 2 -------------------------------------------------------------------
     def compute_path_constraints(self):
@@ -1267,7 +1355,7 @@ class _SegIndexView:
         for t in o._seg_tids:
             out[chroms[t]] = {}
         for row, key in zip(o._e_row.tolist(), o._e_key.tolist()):
-            out[chroms[T.tid[row]]].setdefault(key & 0xFFFFFFFF, []).append(o._chim_names[T.read[row]])
+            out[chroms[T.tid[row]]].setdefault(key & 0xFFFFFFFF, []).append(o.chimeric_alignments._names[T.read[row]])
         return out
 
     def __contains__(self, c):

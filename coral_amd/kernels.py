@@ -23,15 +23,25 @@ class ScanResult:
     """Per-record CIGAR summaries of the local shard (device tensors) and the large-gap rows of ALL shards.
 
     gaps: int64 [K, 6] = record ordinal (global), op index of the next block, previous block end, next block start,
-    first block start, last block end of that record; sorted by (record, op index) — the reference's order.
+    first block start, last block end of that record; sorted by (record, op index) — the reference's order.  On one GPU the
+    rows are fetched from the device the first time they are asked for, so the launch itself never waits for the kernel.
     """
 
-    def __init__(self, mbases, qinfer, blk_first, blk_last, gaps):
+    def __init__(self, mbases, qinfer, blk_first, blk_last, gaps=None, pending=None):
         self.mbases, self.qinfer, self.blk_first, self.blk_last = mbases, qinfer, blk_first, blk_last
-        self.gaps = gaps
+        self._gaps, self._pending = gaps, pending
+
+    @property
+    def gaps(self):
+        if self._gaps is None:
+            self._gaps = self._pending()
+            self._pending = None
+        return self._gaps
 
 
 def _scan_local(dr, min_gap: int, min_mapq: int, gap_cap: int):
+    """Launch coral_cigar_scan on the local shard; returns the four per-record tensors and a callable that yields the gap rows
+    (int64 [K, 6] device tensor, LOCAL record ordinals) — calling it is the first point that waits for the kernel."""
     L = _lib.lib()
     dev = dr.device
     n = dr.n
@@ -40,26 +50,36 @@ def _scan_local(dr, min_gap: int, min_mapq: int, gap_cap: int):
     b0 = torch.empty_like(mb)
     b1 = torch.empty_like(mb)
     rs = dr.c_struct()
-    while True:
-        gaps = torch.empty((gap_cap, 4), dtype=torch.int32, device=dev)
+
+    def launch(cap):
+        gaps = torch.empty((cap, 4), dtype=torch.int32, device=dev)
         cnt = torch.zeros(1, dtype=torch.int32, device=dev)
         prof = PROFILE.get("scan_ms")
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(dev))
         _lib.check(L.coral_cigar_scan(C.byref(rs), min_gap, min_mapq, mb.data_ptr(), qi.data_ptr(), b0.data_ptr(),
-                                      b1.data_ptr(), gaps.data_ptr(), cnt.data_ptr(), gap_cap, dr.stream()),
+                                      b1.data_ptr(), gaps.data_ptr(), cnt.data_ptr(), cap, dr.stream()),
                    "coral_cigar_scan")
         if prof is not None:
             e1.record(torch.cuda.current_stream(dev))
             prof.append((e0, e1))
-        k = int(cnt.item()) & 0xFFFFFFFF
-        if k <= gap_cap:
-            break
-        gap_cap = 1 << int(np.ceil(np.log2(k + 1)))
-    g = gaps[:k].to(torch.int64)
-    rows = torch.cat([g, b0[:n][g[:, 0]].to(torch.int64)[:, None], b1[:n][g[:, 0]].to(torch.int64)[:, None]], dim=1) \
-        if k else torch.zeros((0, 6), dtype=torch.int64, device=dev)
+        return gaps, cnt
+
+    state = [launch(gap_cap), gap_cap]
+
+    def rows():
+        while True:
+            (gaps, cnt), cap = state
+            k = int(cnt.item()) & 0xFFFFFFFF
+            if k <= cap:
+                break
+            cap = 1 << int(np.ceil(np.log2(k + 1)))          # more gap rows than slots: run again with room for all of them
+            state[0], state[1] = launch(cap), cap
+        g = gaps[:k].to(torch.int64)
+        return torch.cat([g, b0[:n][g[:, 0]].to(torch.int64)[:, None], b1[:n][g[:, 0]].to(torch.int64)[:, None]], dim=1) \
+            if k else torch.zeros((0, 6), dtype=torch.int64, device=dev)
+
     return mb[:n], qi[:n], b0[:n], b1[:n], rows
 
 
@@ -67,14 +87,21 @@ def cigar_scan(dr, min_gap: int = 600, min_mapq: int = 20, gap_cap: int = 1 << 1
     from . import sharding
     if dr.world > 1 and not _worker:
         sharding.command(dr, ("scan", min_gap, min_mapq, gap_cap))
-    mb, qi, b0, b1, rows = _scan_local(dr, min_gap, min_mapq, gap_cap)
-    rows[:, 0] += dr.lo
+    mb, qi, b0, b1, pending = _scan_local(dr, min_gap, min_mapq, gap_cap)
+
+    def gather():
+        rows = pending()
+        rows[:, 0] += dr.lo
+        if dr.world > 1:
+            rows = sharding.allgather_rows(dr, rows)
+        g = rows.cpu().numpy()
+        if len(g):
+            g = g[np.lexsort((g[:, 1], g[:, 0]))]      # (record ordinal, op index): the reference's iteration order
+        return g
+
     if dr.world > 1:
-        rows = sharding.allgather_rows(dr, rows)
-    g = rows.cpu().numpy()
-    if len(g):
-        g = g[np.lexsort((g[:, 1], g[:, 0]))]      # (record ordinal, op index): the reference's iteration order
-    return ScanResult(mb, qi, b0, b1, g)
+        return ScanResult(mb, qi, b0, b1, gaps=gather())      # the exchange is a collective: every rank takes part now
+    return ScanResult(mb, qi, b0, b1, pending=gather)
 
 
 def _disjoint_batches(segs: np.ndarray) -> List[np.ndarray]:
@@ -186,10 +213,95 @@ def point_cover(dr, points: Sequence[Tuple[int, int]], pair_cap: int = 1 << 20, 
     return [per_uniq[j] for j in inverse.reshape(-1)]
 
 
+class _PinnedPool:
+    """Page-locked staging buffers for the device -> host copies of one build (the chimeric table and the pair table, tens of
+    MB at 2 M reads): a pageable copy of that size costs several ms on the critical path, a pinned asynchronous one overlaps
+    with the CIGAR scan.  A buffer is leased to ONE ChimericTable for that table's lifetime (the table's numpy arrays are views
+    of it) and re-used afterwards, so consecutive builds alternate between two sets instead of pinning memory every time."""
+    _free: dict = {}
+
+    @classmethod
+    def lease(cls, device, nbytes: int) -> torch.Tensor:
+        if torch.device(device).type != "cuda":
+            return torch.empty(max(nbytes, 1), dtype=torch.uint8)
+        pool = cls._free.setdefault(str(device), [])
+        fits = [k for k, t in enumerate(pool) if nbytes <= t.numel() <= max(4 * nbytes, 1 << 20)]
+        if fits:
+            return pool.pop(min(fits, key=lambda k: pool[k].numel()))
+        return torch.empty(max(int(nbytes * 1.25), 1 << 16), dtype=torch.uint8, pin_memory=True)
+
+    @classmethod
+    def release(cls, device, t: torch.Tensor):
+        if t.is_pinned():
+            pool = cls._free.setdefault(str(device), [])
+            if len(pool) < 16:
+                pool.append(t)
+
+
+class Staged:
+    """Host arrays of one coral_sa_table + coral_bp_pair_table run, landing asynchronously in leased pinned memory."""
+
+    def __init__(self, dr):
+        self.device = dr.device
+        self._leases = []
+        self._side = None
+        if dr.device.type == "cuda":
+            side = getattr(dr, "_copy_stream", None)
+            if side is None:
+                side = dr._copy_stream = torch.cuda.Stream(device=dr.device)
+            self._side = side
+        self.events = {}
+
+    def start(self, name: str, tensors: dict):
+        """Copy the device tensors to pinned host arrays on the copy stream (after everything queued so far on the records'
+        stream); ``wait(name)`` blocks until that group has landed.  Returns {key: numpy view}."""
+        out = {}
+        if self._side is None:
+            return {k: t.numpy() for k, t in tensors.items()}
+        main = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        self._side.wait_event(ready)
+        with torch.cuda.stream(self._side):
+            for k, t in tensors.items():
+                nbytes = t.numel() * t.element_size()
+                buf = _PinnedPool.lease(self.device, nbytes)
+                self._leases.append(buf)
+                host = buf[:nbytes].view(t.dtype).view(t.shape)
+                host.copy_(t, non_blocking=True)
+                t.record_stream(self._side)
+                out[k] = host.numpy()
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self.events[name] = ev
+        return out
+
+    def wait(self, name: str):
+        ev = self.events.pop(name, None)
+        if ev is not None:
+            ev.synchronize()
+
+    def close(self):
+        for ev in self.events.values():
+            ev.synchronize()
+        self.events = {}
+        for buf in self._leases:
+            _PinnedPool.release(self.device, buf)
+        self._leases = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:          # noqa: BLE001 — interpreter shutdown
+            pass
+
+
 def _sa_table_local(dr):
-    """coral_sa_table on this process's GPU over ALL records' SA rows (they are tiny next to the CIGARs; the table is
-    consumed by the host logic, so it is built where that runs).  Returns numpy arrays
-    (rows int32[n_rows, 8], off int64[n_reads + 1], name_id, failed, read_length)."""
+    """coral_sa_table (K3) + coral_bp_pair_table (K4) on this process's GPU over ALL records' SA rows (they are tiny next to
+    the CIGARs; the table is consumed by the host logic, so it is built where that runs).  Returns
+    (cols int64[8, n_rows], off int64[n_reads + 1], name_id, failed, read_length, pairs int32[2 * n_rows, 8], device rows,
+    staging): the host arrays live in ``staging``'s pinned buffers; everything but ``pairs`` has landed on return, ``pairs``
+    after ``staging.wait("pairs")``."""
     L = _lib.lib()
     dev = dr.device
     d = dr.sa_device_arrays()
@@ -219,12 +331,15 @@ def _sa_table_local(dr):
         raise _lib.CoralHipError("coral_sa_table failed (%d): %s" % (rc, L.coral_sa_last_error().decode()))
     n_reads, n_rows = int(counts[0]), int(counts[1])
     pairs = pair_table(dr, out_off, out_rows, n_reads, n_rows)
-    # the rows leave the GPU column by column (transposed there): the host wants seven contiguous int64 columns, and cutting
-    # them out of a row-major [n, 8] array costs more than the whole kernel
-    cols = out_rows[:n_rows].t().contiguous().to(torch.int64).cpu().numpy()
-    return (cols, out_off[:n_reads + 1].cpu().numpy().astype(np.int64),
-            out_name[:n_reads].cpu().numpy().astype(np.int64), out_failed[:n_reads].cpu().numpy().astype(bool),
-            out_rl[:dr.n_names].cpu().numpy().astype(np.int64), pairs[:2 * n_rows].cpu().numpy(), out_rows[:n_rows])
+    # the rows leave the GPU column by column (transposed and widened there): the host wants seven contiguous int64 columns,
+    # and cutting them out of a row-major [n, 8] array costs more than the whole kernel
+    st = Staged(dr)
+    h = st.start("table", dict(cols=out_rows[:n_rows].t().contiguous().to(torch.int64), off=out_off[:n_reads + 1].to(torch.int64),
+                               name=out_name[:n_reads].to(torch.int64), failed=out_failed[:n_reads].to(torch.bool),
+                               rl=out_rl[:dr.n_names].to(torch.int64)))
+    hp = st.start("pairs", dict(pairs=pairs[:2 * n_rows]))
+    st.wait("table")
+    return h["cols"], h["off"], h["name"], h["failed"], h["rl"], hp["pairs"], out_rows[:n_rows], st
 
 
 def pair_table(dr, off: torch.Tensor, rows: torch.Tensor, n_reads: int, n_rows: int, cutoff=100, min_mapq=20, gap_=100,
@@ -243,8 +358,8 @@ def pair_table(dr, off: torch.Tensor, rows: torch.Tensor, n_reads: int, n_rows: 
 
 def sa_table(dr):
     """(columns int64 [8, n_rows] = qs, qe, tid, ra, rb, strand, mapq, nm; row offsets per read; name id per read; failed flag
-    per read; read length per name id; pair table; the rows as they stay on the device) — coral_sa_table + coral_bp_pair_table
-    over all SA rows."""
+    per read; read length per name id; pair table; the rows as they stay on the device; the staging object that owns the host
+    buffers) — coral_sa_table + coral_bp_pair_table over all SA rows."""
     return _sa_table_local(dr)
 
 

@@ -154,15 +154,9 @@ class ReadSupportSet(_LazySet):
         self._chunks = None
 
     def _count(self):
-        nid = np.concatenate([c[0] for c in self._chunks])
-        i = np.concatenate([c[1] for c in self._chunks])
-        j = np.concatenate([c[2] for c in self._chunks])
-        if len(nid) == 0:
-            return 0
-        m = int(max(i.max(), j.max())) + 1
-        if m < (1 << 15) and int(nid.max()) < (1 << 32):
-            return len(np.unique((nid * m + i) * m + j))
-        return len(np.unique(np.stack([nid, i, j], axis=1), axis=0))
+        if len(self._chunks) == 1:
+            return _pyobjects.count_distinct3(*self._chunks[0])
+        return _pyobjects.count_distinct3(*(np.concatenate([c[k] for c in self._chunks]) for k in range(3)))
 
     def __ior__(self, other):
         if self._set is None and isinstance(other, ReadSupportSet) and other._set is None and other._names is self._names:
@@ -179,27 +173,31 @@ class ReadSupportSet(_LazySet):
 
 
 class ReadNameSet(_LazySet):
-    """``set`` of read names given as the name-id arrays of the two point fetches whose union it is (``rls | rrs``, ibg:1054):
-    materialised as ``set(names of the first) | set(names of the second)``, each in fetch order."""
-    __slots__ = ("_left", "_right")
+    """``set`` of read names given as the record ordinals of the two point fetches whose union it is (``rls | rrs``, ibg:1054)
+    and the records' name ids: materialised as ``set(names of the first) | set(names of the second)``, each in fetch order."""
+    __slots__ = ("_rec_name", "_left", "_right")
 
-    def __init__(self, names, left_ids, right_ids):
+    def __init__(self, names, rec_name, left_recs, right_recs):
         self._names = names
         self._set = None
         self._size = None
-        self._left = np.ascontiguousarray(left_ids, dtype=np.int64)
-        self._right = np.ascontiguousarray(right_ids, dtype=np.int64)
+        self._rec_name = rec_name
+        self._left = left_recs
+        self._right = right_recs
+
+    def _ids(self, recs):
+        return np.ascontiguousarray(self._rec_name[recs], dtype=np.int64)
 
     def _build(self):
-        return set(_pyobjects.names_of(self._names, self._left)) | set(_pyobjects.names_of(self._names, self._right))
+        return set(_pyobjects.names_of(self._names, self._ids(self._left))) | set(_pyobjects.names_of(self._names, self._ids(self._right)))
 
     def _drop_arrays(self):
-        self._left = self._right = None
+        self._left = self._right = self._rec_name = None
 
     def _count(self):
-        return len(np.union1d(self._left, self._right))
+        return len(self.name_ids())
 
     def name_ids(self):
         if self._set is not None:
             return None
-        return np.union1d(self._left, self._right)
+        return np.union1d(self._ids(self._left), self._ids(self._right))

@@ -181,14 +181,17 @@ int coral_bp_pair_table(int32_t n_reads, int32_t n_rows, const int32_t *off, con
  * coral_search_step(tid, s, e, si, ei): reach sets (ibg:369-384, replayed as CPython sets: size and iteration order),
  * segments with fewer reads than the cutoff dropped, runs of neighbouring segments (ibg:392-419), for every run alignment2bp
  * of the united set's reads, in the set's iteration order, between the run and (tid, s, e), and coral_call_breakpoints on
- * every run's candidates (ibg:436-457; sub-cluster counter not advanced, Appendix A Q4) — coral_search_calls(group) returns
- * that function's outputs.  A step is a pure function of its arguments: coral_search_prefetch asks for it to be computed
+ * every run's candidates (ibg:436-457; sub-cluster counter not advanced, Appendix A Q4).  A step is a pure function of its arguments: coral_search_prefetch asks for it to be computed
  * ahead on a worker thread, coral_search_step then waits for / takes over / computes it; results do not depend on timing.
  * coral_search_within: alignment2bp_l of every read in table order.  coral_search_between: alignment2bp
  * of the listed reads between two intervals.  coral_search_result then gives (valid until the next call on the handle)
- * groups int64[n_groups][4] = contig id, first segment, last segment, candidates of the run; cand int64[n_cand][13] =
- * c1, p1, o1, c2, p2, o2, read name id, i, j, query gap, swapped, mapq a, mapq b (the 11 fields of bu:81 / bu:294-295);
- * order_off int64[n_groups + 1] / order int32[] = the reads of every run in iteration order (table indices).
+ *   cand int64[n_cand][13] = c1, p1, o1, c2, p2, o2, read name id, i, j, query gap, swapped, mapq a, mapq b (the 11 fields
+ *        of bu:81 / bu:294-295), the runs' candidates one after the other;
+ *   meta int64[n_meta] = n_groups, then per run: contig id, first segment, last segment, n candidates, n clusters, n calls,
+ *        the cluster sizes, and per call: head candidate, p1, p2, flags, begin and end of its support in `sup` (head and
+ *        support indices are relative to the run's first candidate; flags as coral_call_breakpoints);
+ *   stats double[6 per call], sup int64[n_sup];
+ *   order_off int64[n_groups + 1] / order int32[] = the reads of every run in iteration order (table indices).
  * CORAL_ERR_FORMAT: a candidate touches a contig outside chr1..22,X,Y,M (KeyError at bu:293 in the reference).
  * ------------------------------------------------------------------------------------------------ */
 void *coral_search_create(int64_t n_reads, int64_t n_rows, const int64_t *off, const int64_t *row_read, const int64_t *row_tid,
@@ -202,14 +205,12 @@ int coral_search_params(void *handle, double min_cluster_cutoff, int64_t max_seq
                         int64_t match_cutoff, double accept_floor, int32_t n_threads);
 int coral_search_prefetch(void *handle, int64_t tid, int64_t s, int64_t e, int64_t si, int64_t ei);
 int coral_search_step(void *handle, int64_t tid, int64_t s, int64_t e, int64_t si, int64_t ei);
-int coral_search_calls(void *handle, int64_t group, int32_t *n_clusters, const int32_t **cluster_size, int32_t *n_calls,
-                       const int64_t **head, const int64_t **p1, const int64_t **p2, const double **stats,
-                       const int32_t **flags, const int64_t **sup_off, const int64_t **sup_idx);
 int coral_search_within(void *handle, int32_t n_int, const int64_t *int_tid, const int64_t *int_start, const int64_t *int_end);
 int coral_search_between(void *handle, int64_t n_sel, const int32_t *reads, int64_t t1, int64_t s1, int64_t e1, int64_t t2,
                          int64_t s2, int64_t e2);
-int coral_search_result(void *handle, int64_t *n_groups, const int64_t **groups, int64_t *n_cand, const int64_t **cand,
-                        const int64_t **order_off, const int32_t **order);
+int coral_search_result(void *handle, int64_t *n_meta, const int64_t **meta, int64_t *n_cand, const int64_t **cand,
+                        int64_t *n_sup, const int64_t **sup, const double **stats, const int64_t **order_off,
+                        const int32_t **order);
 
 /* ------------------------------------------------------------------------------------------------
  * coral_read_counter — copy a device counter to the host (synchronises `stream`).
@@ -290,6 +291,13 @@ int coral_call_breakpoints(int64_t n, const int64_t *const *field_ptr, const int
  * CORAL_ERR_ZERODIV when a counted record has query_length 0 (no SEQ): the reference raises ZeroDivisionError at ibg:154. */
 int coral_nm_stats(int64_t n, const int32_t *tid, const int64_t *sa_off, const int32_t *mapq, const int32_t *nm,
                    const int32_t *qlen, int64_t *count, double *sum_e, double *sum_e2);
+
+/* Long-read support of the concordant edges (ibg:1043-1055): for edge q, pt_rec[pt_off[4q + d] .. pt_off[4q + d + 1]) are the
+ * record ordinals covering its position d (p, p + 1, p - 101, p + 101: coral_point_cover), rec_name int32[n_rec] maps records
+ * to read-name ids, sup_name[sup_off[q] .. sup_off[q + 1]) are the name ids supporting a discordant edge at either node of the
+ * edge; count[q] = number of distinct names covering all four positions and not among those.  Host arrays. */
+int coral_concordant_counts(int32_t n_edges, const int64_t *pt_off, const int64_t *pt_rec, const int32_t *rec_name, int64_t n_rec,
+                            int64_t n_names, const int64_t *sup_off, const int64_t *sup_name, int64_t *count);
 
 /* Reachable CN segments of one amplicon interval — the traversal of ibg:369-384 with the read-name sets replayed natively.
  * visit_rows[n_visit]: rows of the chimeric table hashed to segments si..ei of chromosome `tid`, in the reference's visiting

@@ -195,7 +195,7 @@ def install_cpu_kernel_fakes(monkeypatch):
                     if abs(bl[k + 1][0] - bl[k][1]) > min_gap:
                         rows.append((i - dr.lo, k + 1, bl[k][1], bl[k + 1][0], b0[-1], b1[-1]))
         t = lambda x: torch.tensor(x, dtype=torch.int32)
-        return t(mb), t(qi), t(b0), t(b1), torch.tensor(rows, dtype=torch.int64).reshape(-1, 6)
+        return t(mb), t(qi), t(b0), t(b1), lambda: torch.tensor(rows, dtype=torch.int64).reshape(-1, 6)
 
     def coverage_local(dr, scan, sg):
         h = host_of(dr)
@@ -239,7 +239,7 @@ def install_cpu_kernel_fakes(monkeypatch):
             rl[name_id_of[rn]] = v
         cols = np.ascontiguousarray(np.array(rows, dtype=np.int64).reshape(-1, 8).T)          # [8, n_rows], as the product's wrapper
         return (cols, np.array(off, dtype=np.int64), np.array(names, dtype=np.int64),
-                np.array(failed, dtype=bool), rl, pair_table_cpu(cols, off, h.chroms, dr.chr_rank), None)
+                np.array(failed, dtype=bool), rl, pair_table_cpu(cols, off, h.chroms, dr.chr_rank), None, None)
 
     def hash_rows_local(dr, T, seg, tid_has_segs):
         """coral_hash_rows stand-in: point queries by linear search over the segment table (the reference's IntervalTree

@@ -133,3 +133,40 @@ def test_nm_stats_equals_sequential_python_sums():
             b += e * e
             k += 1
     assert (cnt.value, s0.value, s1.value) == (k, a, b) and k > 1000
+
+
+def test_concordant_counts_equal_python_sets():
+    """coral_concordant_counts vs the reference's set algebra (ibg:1043-1055): |(rls & rrs & rls1 & rrs1) - rbps| per edge."""
+    import ctypes as C
+    import numpy as np
+    from coral_amd import _lib
+    rng = np.random.default_rng(9)
+    n_rec, n_names, n_edges = 4000, 1500, 23
+    rec_name = rng.integers(0, n_names, n_rec).astype(np.int32)
+    cover, sup, expect = [], [], []
+    for q in range(n_edges):
+        lists = [rng.choice(n_rec, size=int(rng.integers(0, 900)), replace=False) for _ in range(4)]
+        if q % 7 == 0:
+            lists[2] = lists[0]
+        s_ = rng.integers(0, n_names, int(rng.integers(0, 300)))
+        cover += lists
+        sup.append(s_)
+        sets = [set(rec_name[l].tolist()) for l in lists]
+        expect.append(len((sets[0] & sets[1] & sets[2] & sets[3]) - set(s_.tolist())))
+    pt_off = np.concatenate([[0], np.cumsum([len(c) for c in cover])]).astype(np.int64)
+    pt_rec = np.concatenate(cover).astype(np.int64)
+    sup_off = np.concatenate([[0], np.cumsum([len(x) for x in sup])]).astype(np.int64)
+    sup_all = np.concatenate(sup).astype(np.int64)
+    out = np.zeros(n_edges, dtype=np.int64)
+    assert _lib.lib().coral_concordant_counts(n_edges, pt_off.ctypes.data, pt_rec.ctypes.data, rec_name.ctypes.data, n_rec, n_names,
+                                              sup_off.ctypes.data, sup_all.ctypes.data, out.ctypes.data) == 0
+    assert out.tolist() == expect and sum(expect) > 50
+
+
+def test_count_distinct3():
+    import numpy as np
+    from coral_amd import _pyobjects as P
+    rng = np.random.default_rng(2)
+    for n in (0, 1, 7, 5000):
+        a, b, c = (rng.integers(0, 40, n).astype(np.int64) for _ in range(3))
+        assert P.count_distinct3(a, b, c) == len(set(zip(a.tolist(), b.tolist(), c.tolist())))
