@@ -15,6 +15,8 @@
 // order-dependent rest of the search (addbp, interval refinement) then finds the result ready (coral_search_step).
 // coral_search_within is the pair filter for alignment2bp_l over all chimeric reads (find_breakpoints, ibg:676-690).
 #include <math.h>
+#include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -40,11 +42,15 @@ using coral_detail::PySetEmu;
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // Per-read data packed for the two hot loops (reach sets, pair filter): one contiguous record per read instead of seven
-// parallel arrays, so a read costs one or two cache lines.  Record = {n rows, first table row} then per row
-// {contig, ra, rb, cni0, cni1, bits of pair (k, k + 1), bits of pair (k - 1, k + 1)}.
+// parallel arrays plus a 32-byte-per-slot table, so a read costs one or two cache lines.  Record = {n rows, first table row}
+// then per row {contig, ra, rb, cni0, cni1, bits of pair (k - 1, k + 1), and the whole pair-table slot of pair (k, k + 1):
+// c1, p1, c2, p2, gap, bits}.  Candidates of adjacent pairs (almost all of them) are emitted from the record itself; the
+// rare skip-one candidates read their slot of the pair table.
 struct PackedRow {
-    int32_t tid, ra, rb, cni0, cni1, bits_adj, bits_skip;
+    int32_t tid, ra, rb, cni0, cni1, bits_skip;
+    int32_t c1, p1, c2, p2, gap, bits_adj;
 };
+static_assert(sizeof(PackedRow) == 48, "PackedRow layout");
 
 struct Calls {                                            // coral_call_breakpoints on one run's candidates
     int32_t n_clusters = 0, n_calls = 0;
@@ -153,6 +159,19 @@ inline bool row_in(const PackedRow &w, int64_t t, int64_t s, int64_t e) {
     return w.tid == t && w.ra <= e && s <= w.rb;
 }
 
+inline bool emit_fields(const Search &S, std::vector<int64_t> &cand, const int32_t *p, int32_t bits, int64_t ia, int64_t ib, int64_t read) {
+    const bool swapped = (bits & 16) != 0;
+    const int64_t row[13] = {p[0], p[1], (bits >> 2) & 1, p[2], p[3], (bits >> 3) & 1, S.read_name[read], swapped ? ib : ia,
+                             swapped ? ia : ib, p[4], swapped ? 1 : 0, (bits >> 8) & 0xff, (bits >> 16) & 0xff};
+    cand.insert(cand.end(), row, row + 13);
+    return (bits & 128) == 0;                  // false: a contig outside chr1..22,X,Y,M reaches interval2bp (KeyError, bu:293)
+}
+
+// adjacent pair (k, k + 1): everything is in the packed record
+inline bool emit_adj(const Search &S, std::vector<int64_t> &cand, const PackedRow &w, int64_t k, int64_t read) {
+    return emit_fields(S, cand, &w.c1, w.bits_adj, k, k + 1, read);
+}
+
 inline bool emit(const Search &S, std::vector<int64_t> &cand, int64_t slot, int64_t read, int64_t base) {
     const int32_t *p = S.pairs + 8 * slot;
     const int32_t bits = p[5];
@@ -177,7 +196,7 @@ inline bool pairs_between(const Search &S, Scratch &T, std::vector<int64_t> &can
         if (!(w[k].bits_adj & 2)) continue;
         if ((row_in(w[k], t1, s1, e1) && row_in(w[k + 1], t2, s2, e2)) || (row_in(w[k + 1], t1, s1, e1) && row_in(w[k], t2, s2, e2))) {
             T.used[(size_t)k] = 1;
-            ok &= emit(S, cand, 2 * (base + k), r, base);
+            ok &= emit_adj(S, cand, w[k], k, r);
         }
     }
     for (int64_t k = 1; k + 1 < n; ++k) {                     // pairs (k - 1, k + 1) around a low-MAPQ alignment
@@ -245,7 +264,11 @@ void compute_step(Search &S, Scratch &T, const int64_t key[5], StepResult &R) {
     const int64_t *rows_e = S.e_row + (lo - S.e_key);
     const int64_t n_visit = hi - lo;
     for (int64_t v = 0; v < n_visit; ++v) {
-        if (v + 8 < n_visit) __builtin_prefetch(&S.row_read[rows_e[v + 8]]);
+        if (v + 12 < n_visit) __builtin_prefetch(&S.row_read[rows_e[v + 12]]);
+        if (v + 5 < n_visit) {
+            const int64_t rr = rows_e[v + 5];
+            if (rr >= 0 && rr < S.n_rows) __builtin_prefetch(S.pack.data() + S.pack_off[(size_t)S.row_read[rr]]);
+        }
         const int64_t row = rows_e[v];
         if (row < 0 || row >= S.n_rows) return fail(CORAL_ERR_ARG, "search_step: row out of range");
         const int64_t r = S.row_read[row];
@@ -351,6 +374,33 @@ void compute_step(Search &S, Scratch &T, const int64_t key[5], StepResult &R) {
     }
 }
 
+// CPUs of the NUMA node the calling thread runs on (empty when it cannot be told): the workers share the chimeric table with the
+// caller, whose pages were first touched there; on the other socket every lookup of the search is a remote access.
+std::vector<int> cpus_of_my_node() {
+    std::vector<int> out;
+    const int cpu = sched_getcpu();
+    if (cpu < 0) return out;
+    for (int node = 0; node < 64; ++node) {
+        char path[96];
+        snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+        FILE *fp = fopen(path, "r");
+        if (!fp) break;
+        char buf[4096];
+        std::vector<int> cpus;
+        if (fgets(buf, sizeof(buf), fp)) {
+            for (char *tok = strtok(buf, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+                int a = 0, b = 0;
+                const int n = sscanf(tok, "%d-%d", &a, &b);
+                if (n == 1) b = a;
+                if (n >= 1) for (int c = a; c <= b; ++c) cpus.push_back(c);
+            }
+        }
+        fclose(fp);
+        if (std::find(cpus.begin(), cpus.end(), cpu) != cpus.end()) return cpus;
+    }
+    return out;
+}
+
 void worker_main(Search *S) {
     Scratch T;
     for (;;) {
@@ -391,7 +441,7 @@ extern "C" void *coral_search_create(int64_t n_reads, int64_t n_rows, const int6
     S->off = off; S->row_read = row_read; S->read_hash = read_hash; S->read_name = read_name; S->e_key = e_key; S->e_row = e_row;
     S->pairs = pairs; S->n_tid = n_tid; S->seg_off = seg_off; S->seg_start = seg_start; S->seg_end = seg_end;
     S->pack_off.resize((size_t)n_reads);
-    S->pack.reserve((size_t)(2 * n_reads + 7 * n_rows));
+    S->pack.reserve((size_t)(2 * n_reads + 12 * n_rows));
     for (int64_t r = 0; r < n_reads; ++r) {
         const int64_t base = off[r], n = off[r + 1] - base;
         if (n < 0 || base < 0 || base + n > n_rows) { delete S; return nullptr; }
@@ -399,9 +449,10 @@ extern "C" void *coral_search_create(int64_t n_reads, int64_t n_rows, const int6
         S->pack.push_back((int32_t)n);
         S->pack.push_back((int32_t)base);
         for (int64_t k = base; k < base + n; ++k) {
-            const int32_t w[7] = {(int32_t)row_tid[k], (int32_t)ra[k], (int32_t)rb[k], (int32_t)cni0[k], (int32_t)cni1[k],
-                                  pairs[8 * (2 * k) + 5], pairs[8 * (2 * k + 1) + 5]};
-            S->pack.insert(S->pack.end(), w, w + 7);
+            const int32_t *adj = pairs + 8 * (2 * k);
+            const int32_t w[12] = {(int32_t)row_tid[k], (int32_t)ra[k], (int32_t)rb[k], (int32_t)cni0[k], (int32_t)cni1[k],
+                                   pairs[8 * (2 * k + 1) + 5], adj[0], adj[1], adj[2], adj[3], adj[4], adj[5]};
+            S->pack.insert(S->pack.end(), w, w + 12);
         }
     }
     const char *pe = getenv("CORAL_SEARCH_PROFILE");
@@ -419,7 +470,16 @@ extern "C" int coral_search_params(void *h, double min_cluster_cutoff, int64_t m
     if (!S.workers.empty() || !S.cache.empty()) return CORAL_ERR_ARG;          // set once, before the first step
     S.min_cluster_cutoff = min_cluster_cutoff; S.max_seq_len = max_seq_len; S.bp_distance_cutoff = bp_distance_cutoff;
     S.match_cutoff = match_cutoff; S.accept_floor = accept_floor;
-    for (int32_t k = 0; k < n_threads; ++k) S.workers.emplace_back(worker_main, &S);
+    const std::vector<int> cpus = n_threads > 0 ? cpus_of_my_node() : std::vector<int>();
+    for (int32_t k = 0; k < n_threads; ++k) {
+        S.workers.emplace_back(worker_main, &S);
+        if (!cpus.empty()) {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            for (int c : cpus) if (c < CPU_SETSIZE) CPU_SET(c, &set);
+            (void)pthread_setaffinity_np(S.workers.back().native_handle(), sizeof(set), &set);
+        }
+    }
     return CORAL_OK;
 }
 
@@ -551,7 +611,7 @@ extern "C" int coral_search_within(void *h, int32_t n_int, const int64_t *int_ti
             if (!(bits & 2) || fi[(size_t)k] < 0 || fi[(size_t)k] != fi[(size_t)k + 1]) continue;
             if ((bits & 32) || (bits & 64)) {
                 used[(size_t)k] = 1;
-                contigs_ok &= emit(S, R.cand, 2 * (base + k), r, base);
+                contigs_ok &= emit_adj(S, R.cand, w[k], k, r);
             }
         }
         for (int64_t k = 1; k + 1 < n; ++k) {

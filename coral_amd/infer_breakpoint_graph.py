@@ -392,14 +392,14 @@ class bam_to_breakpoint_nanopore():
 
     # ---- A3 ----------------------------------------------------------------------------------
     def launch_record_kernels(self):
-        """Issue the two passes that depend on the records alone — the SA table (K3) and the fused CIGAR scan — back to back,
-        before any host logic runs: the scan then starts on a GPU that is already clocked up instead of after the host-side
-        gap between two steps.  What fetch() would raise is kept and raised there."""
+        """Issue the two passes that depend on the records alone before any host logic runs: the fused CIGAR scan (launched
+        without waiting for it) and, on a stream of their own, the SA table + pair table (K3, K4), whose host round trips then
+        overlap with the scan.  What fetch() would raise is kept and raised there."""
+        self.scan()
         try:
             self._chim_early = build_chimeric_table(self.rec)
         except Exception as exc:                      # noqa: BLE001 — re-raised by fetch(), where the reference raises
             self._chim_early = exc
-        self.scan()
 
     def fetch(self):
         """Collect chimeric alignments of every read from the SA tags (ibg:139-174)."""
@@ -957,16 +957,12 @@ class bam_to_breakpoint_nanopore():
             o = np.argsort(rank[inv], kind="stable")
             grp = rank[inv][o]
             k_in = np.arange(len(o)) - np.searchsorted(grp, grp, side="left")
-            chroms = dr.header_chroms
-            lia = self.large_indel_alignments
             ro = rec[o]
-            rows = list(map(list, zip(itemgetter(*dr.h_tid[ro].tolist())(chroms) if len(o) > 1 else [chroms[dr.h_tid[ro[0]]]],
-                                      nxt[o].tolist(), prv[o].tolist(), b0[o].tolist(), b1[o].tolist(),
-                                      dr.h_mapq[ro].tolist())))
-            starts = np.nonzero(k_in == 0)[0].tolist() + [len(o)]
-            gnames = self._names_of(nid[o][starts[:-1]])
-            for gi, nm in enumerate(gnames):                       # names are distinct per group (grouped above)
-                lia[nm] = rows[starts[gi]:starts[gi + 1]]
+            starts = np.nonzero(k_in == 0)[0]
+            # name -> [[chr, next block start, previous block end, first block start, last block end, mapq], ...] (ibg:746-762),
+            # names in first-appearance order; the Python lists are made when the dict is first looked into
+            self.large_indel_alignments = _LazyIndelAlignments(self, nid[o][starts], np.append(starts, len(o)), dr.h_tid[ro], nxt[o], prv[o],
+                                                               b0[o], b1[o], dr.h_mapq[ro])
             a = nxt[o]
             b = np.minimum(prv[o], a)                                            # aliasing swap (Q7)
             tid = dr.h_tid[rec[o]].astype(np.int64)
@@ -1301,6 +1297,103 @@ class bam_to_breakpoint_nanopore():
 
     def closebam(self):
         self.lr_bamfh.close()
+
+
+class _LazyIndelAlignments(dict):
+    """``large_indel_alignments``: read name -> list of ``[chr, next block start, previous block end, first block start, last
+    block end, mapq]`` (ibg:746-762), names in first-appearance order.  Built from arrays on first use; only ``len()`` is
+    answered without building."""
+
+    def __init__(self, owner, group_name_ids, bounds, tid, nxt, prv, b0, b1, mapq):
+        super().__init__()
+        self._src = (weakref.proxy(owner), group_name_ids, bounds, tid, nxt, prv, b0, b1, mapq)
+        self._n = len(group_name_ids)
+
+    def _fill(self):
+        if self._src is not None:
+            o, gids, bounds, tid, nxt, prv, b0, b1, mapq = self._src
+            self._src = None
+            chroms = o.rec.header_chroms
+            rows = list(map(list, zip([chroms[t] for t in tid.tolist()], nxt.tolist(), prv.tolist(), b0.tolist(), b1.tolist(),
+                                      mapq.tolist())))
+            names = o._names_of(gids)
+            bnd = bounds.tolist()
+            dict.update(self, {nm: rows[bnd[k]:bnd[k + 1]] for k, nm in enumerate(names)})
+
+    def __len__(self):
+        return self._n if self._src is not None else dict.__len__(self)
+
+    def __bool__(self):
+        return len(self) > 0
+
+    def __contains__(self, k):
+        self._fill()
+        return dict.__contains__(self, k)
+
+    def __getitem__(self, k):
+        self._fill()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        self._fill()
+        return dict.get(self, k, default)
+
+    def __iter__(self):
+        self._fill()
+        return dict.__iter__(self)
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+    def values(self):
+        self._fill()
+        return dict.values(self)
+
+    def __setitem__(self, k, v):
+        self._fill()
+        dict.__setitem__(self, k, v)
+
+    def __delitem__(self, k):
+        self._fill()
+        dict.__delitem__(self, k)
+
+    def setdefault(self, k, default=None):
+        self._fill()
+        return dict.setdefault(self, k, default)
+
+    def pop(self, k, *default):
+        self._fill()
+        return dict.pop(self, k, *default)
+
+    def update(self, *a, **kw):
+        self._fill()
+        dict.update(self, *a, **kw)
+
+    def copy(self):
+        self._fill()
+        return dict(self)
+
+    def __eq__(self, other):
+        self._fill()
+        return dict.__eq__(self, other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        self._fill()
+        return dict.__repr__(self)
+
+    def __reduce__(self):
+        self._fill()
+        return (dict, (list(dict.items(self)),))
 
 
 class _LazyReadLength(dict):

@@ -302,9 +302,22 @@ def _sa_table_local(dr):
     (cols int64[8, n_rows], off int64[n_reads + 1], name_id, failed, read_length, pairs int32[2 * n_rows, 8], device rows,
     staging): the host arrays live in ``staging``'s pinned buffers; everything but ``pairs`` has landed on return, ``pairs``
     after ``staging.wait("pairs")``."""
+    d = dr.sa_device_arrays()
+    if dr.device.type != "cuda":
+        return _sa_table_on_current_stream(dr, d)
+    # on a stream of its own: the table kernels are tiny and have three host round trips, the CIGAR scan launched just before
+    # on the records' stream keeps the GPU busy meanwhile
+    side = getattr(dr, "_table_stream", None)
+    if side is None:
+        side = dr._table_stream = torch.cuda.Stream(device=dr.device)
+    side.wait_stream(torch.cuda.current_stream(dr.device))
+    with torch.cuda.stream(side):
+        return _sa_table_on_current_stream(dr, d)
+
+
+def _sa_table_on_current_stream(dr, d):
     L = _lib.lib()
     dev = dr.device
-    d = dr.sa_device_arrays()
     n_sa = dr.n_sa
     ws_bytes = max(1 << 20, 104 * max(n_sa, 1) + 8 * dr.n_names + (8 << 20))
     out_rows = torch.empty((max(n_sa, 1), 8), dtype=torch.int32, device=dev)

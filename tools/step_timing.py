@@ -1,4 +1,4 @@
-"""Where does a step's wall time go outside the phases? (alloc/free of the previous result, gc, ...)"""
+"""Per-step wall time against the per-phase times of build_graph_from_records (where do slow steps lose their time?)."""
 import sys, os, time, tempfile, gc
 sys.path.insert(0, ".")
 import torch
@@ -11,13 +11,13 @@ synth.write_cn_bed(cfg, cn); synth.write_seed_bed(cfg, seeds)
 rec = synth.generate(cfg, "cuda:0", chunk_pieces=200000); torch.cuda.synchronize()
 dr = sharding.shard_records(rec, 0, 1, "cuda:0"); del rec
 b = None
-for i in range(5):
+for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
     t0 = time.perf_counter()
     nb = sharding.build_graph_sharded(dr, seeds, cn, os.path.join(work, "p%d" % i))
     t1 = time.perf_counter()
+    ph = dict(ibg.PHASE_SECONDS)
     b = nb            # frees the previous step's result
     nb = None
     t2 = time.perf_counter()
-    t3 = time.perf_counter(); x = [[] for _ in range(2000)]; t4 = time.perf_counter()      # allocations that trip the collector
-    print("   first allocations after the build: %.1f ms" % ((t4 - t3) * 1e3))
-    print("step %d: build %.1f ms (phases sum %.1f ms) free-previous %.1f ms gc counts %s" % (i, (t1 - t0) * 1e3, sum(ibg.PHASE_SECONDS.values()) * 1e3, (t2 - t1) * 1e3, gc.get_count()), flush=True)
+    print("step %2d: build %6.1f ms  phases sum %6.1f  free-previous %5.1f  | %s" % (
+        i, (t1 - t0) * 1e3, sum(ph.values()) * 1e3, (t2 - t1) * 1e3, " ".join("%s %.1f" % (k[:9], v * 1e3) for k, v in ph.items())), flush=True)
