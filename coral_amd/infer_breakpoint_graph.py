@@ -32,7 +32,7 @@ import numpy as np
 import os
 import weakref
 
-from . import _lib, global_names, kernels
+from . import _lib, global_names, hostpools, kernels
 from . import _pyobjects          # CPython extension built by __graft_entry__.build(); no Python fallback
 from .bpcluster import call_breakpoints
 from .breakpoint_graph import BreakpointGraph, compute_cn_lr, output_breakpoint_graph_lr, output_breakpoint_info_lr
@@ -1480,7 +1480,8 @@ def build_graph_from_records(records, seedfile, cn_seg, output_prefix=None, min_
     if gc_policy != "none":
         gc.disable()
     try:
-        b2bn = _build_graph_from_records(records, seedfile, cn_seg, output_prefix, min_bp_support, output_bp, graph_class)
+        with hostpools.limited():
+            b2bn = _build_graph_from_records(records, seedfile, cn_seg, output_prefix, min_bp_support, output_bp, graph_class)
         if gc_policy == "freeze":
             gc.freeze()
         return b2bn
