@@ -15,7 +15,7 @@ import os
 # the host side is one thread + a few native workers: per-core OpenMP / BLAS pools only spin (and, under a container CPU quota,
 # get the process throttled); set before numpy / torch are imported
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-    os.environ.setdefault(_v, "4")
+    os.environ.setdefault(_v, "1" if _v.startswith("OPENBLAS") else "4")
 import shutil
 import sys
 import tempfile

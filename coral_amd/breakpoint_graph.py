@@ -449,26 +449,12 @@ def solve_cn_lr(w_inv, w_lin, w_log, A, max_iter=200):
 solve_cn_lr.last_residual = 0.0
 
 
-_blas = None
-
-
-def _single_threaded_blas():
-    """The CN systems are ~100 x 100: BLAS worker threads only add hand-off latency there (and, next to another OpenMP pool
-    in the process, two orders of magnitude of spinning).  One controller per process; entering the limit is cheap."""
-    global _blas
-    if _blas is None:
-        from threadpoolctl import ThreadpoolController
-        _blas = ThreadpoolController()
-    return _blas.limit(limits=1, user_api="blas")
-
-
 def compute_cn_lr(g, normal_cov_lr):
     """Fill the CN field of every edge of ``g`` and ``g.max_cn`` (bg:495-606)."""
     ls, lc, ld = len(g.sequence_edges), len(g.concordant_edges), len(g.discordant_edges)
     w_inv, w_lin, w_log, A = cn_problem(g, normal_cov_lr)
     if A.shape[0] > 0:
-        with _single_threaded_blas():
-            x = solve_cn_lr(w_inv, w_lin, w_log, A)
+        x = solve_cn_lr(w_inv, w_lin, w_log, A)
         doubled = [float(v) * 2 for v in x]
         for k in range(ls):
             g.sequence_edges[k][-1] = doubled[k]

@@ -1,36 +1,29 @@
-"""Host thread pools (OpenMP, BLAS) during a graph build.
+"""Host BLAS thread pools and the graph build.
 
-The host side of the build is a single thread plus the few native search workers of coral_search_*; its numpy / scipy / torch
-calls work on arrays of a few hundred kilobytes at most.  On a many-core host the default OpenMP / OpenBLAS pools (one thread
-per core, spinning between parallel regions) burn far more CPU time than the build itself — under a container CPU quota
-(cgroup ``cpu.max``) that gets the whole process throttled for tens of milliseconds at a time.  ``limited()`` caps the pools for
-the duration of a build and restores them afterwards; ``CORAL_HOST_THREADS`` (default 4) sets the cap, ``0`` leaves the pools alone.
+The host side of the build is a single thread plus the few native search workers of coral_search_*; its only dense linear
+algebra is the CN assignment, systems of ~100 unknowns.  numpy and scipy each bring an OpenBLAS pool with one thread per core
+(64 on the MI355X hosts), and every multi-threaded BLAS call — or every change of the pool size — leaves those threads spinning
+for a while.  That costs far more CPU time than the build itself, and under a container CPU quota (cgroup ``cpu.max``) it gets
+the whole process throttled for tens of milliseconds at a time (measured: 13 throttling events in 10 builds).  So the first
+build of a process sets the BLAS pools to ONE thread, for the rest of the process (flipping the size per build is exactly what
+wakes the spinners).  ``CORAL_HOST_THREADS=0`` leaves the pools alone; any other value is the BLAS thread count to set.
+Exporting ``OPENBLAS_NUM_THREADS`` / ``OMP_NUM_THREADS`` before starting Python (bench.py and the CLI do) avoids creating the
+threads in the first place.
 """
 from __future__ import annotations
 
-import contextlib
 import os
 
-_controller = None
+_applied = None          # keeps the threadpoolctl limiter alive: its destructor would restore the old sizes
 
 
-@contextlib.contextmanager
-def limited():
-    n = int(os.environ.get("CORAL_HOST_THREADS", "4"))
-    if n <= 0:
-        yield
+def apply_once():
+    global _applied
+    if _applied is not None:
         return
-    global _controller
-    import torch
-    if _controller is None:
-        from threadpoolctl import ThreadpoolController
-        _controller = ThreadpoolController()
-    before = torch.get_num_threads()
-    if before > n:
-        torch.set_num_threads(n)
-    try:
-        with _controller.limit(limits=n):
-            yield
-    finally:
-        if before > n:
-            torch.set_num_threads(before)
+    n = int(os.environ.get("CORAL_HOST_THREADS", "1"))
+    if n <= 0:
+        _applied = False
+        return
+    from threadpoolctl import threadpool_limits
+    _applied = threadpool_limits(limits=n, user_api="blas")

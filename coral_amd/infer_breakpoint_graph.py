@@ -1480,8 +1480,8 @@ def build_graph_from_records(records, seedfile, cn_seg, output_prefix=None, min_
     if gc_policy != "none":
         gc.disable()
     try:
-        with hostpools.limited():
-            b2bn = _build_graph_from_records(records, seedfile, cn_seg, output_prefix, min_bp_support, output_bp, graph_class)
+        hostpools.apply_once()
+        b2bn = _build_graph_from_records(records, seedfile, cn_seg, output_prefix, min_bp_support, output_bp, graph_class)
         if gc_policy == "freeze":
             gc.freeze()
         return b2bn
