@@ -25,5 +25,6 @@ def apply_once():
     if n <= 0:
         _applied = False
         return
+    import scipy.linalg                      # noqa: F401 — scipy ships its own OpenBLAS: it must be loaded to be limited
     from threadpoolctl import threadpool_limits
     _applied = threadpool_limits(limits=n, user_api="blas")
