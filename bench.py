@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
 """Headline benchmark: reads/s through the breakpoint-graph build on a synthetic long-read amplicon BAM.
 
-    python bench.py --gpus 1 --steps K --warmup W [--config cfg3] [--reads N]
+    python bench.py --gpus 1 --steps K --warmup W [--config cfg3] [--reads N] [--bam-reads M]
 
 One "step" = one full pass of the hot path over the resident batch: decoded records already in HBM ->
-BreakpointGraph objects + *_graph.txt written (Gurobi cycle step skipped), i.e. SURVEY.md §8(d)'s timed region.
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: coral_cigar_scan, HIP-event timed on the launch
-stream inside the timed steps) and `cpu_baseline` (the CPU oracle on a bounded sample of the same workload).
+BreakpointGraph objects + *_graph.txt written (Gurobi cycle step skipped), i.e. the contract's timed region.
+Prints ONE JSON line (rank 0) with
+  `roofline`      dominant kernel (coral_cigar_scan), HIP-event timed on the launch stream inside the timed steps;
+  `h2d_ms` / `value_incl_h2d`   pinned host -> HBM of the resident arrays, measured once, and the rate with it added;
+  `decode`        BGZF/BAM decode throughput of coral_bam_decode_* on a BAM of --bam-reads reads of the same workload;
+  `end_to_end`    BAM file -> graph files (decode of every rank's byte range + upload + build), same BAM;
+  `cpu_baseline`  the CPU oracle on a bounded sample of the same workload, resident (`value`) and from its BAM (`end_to_end`).
 """
 import argparse
 import json
@@ -25,19 +29,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-# name of the kernel behind coral_cigar_scan per coral_set_scan_variant value (0 = library default = 15)
-SCAN_KERNEL_NAME = {0: "k_cigar_scan_v2<8, false, true, 8>", 15: "k_cigar_scan_v2<8, false, true, 8>", 7: "k_cigar_scan_v2<8, false, true, 1>", 3: "k_cigar_scan_v2<8, false, false, 1>",
-                    13: "k_cigar_scan_ring_asm<8, true>", 10: "k_cigar_scan_ring<8, true>", 8: "k_cigar_scan_packed<8>"}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--reads", type=int, default=0, help="override the read count of the config (0 = as configured)")
     ap.add_argument("--cpu-sample", type=int, default=50000, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--bam-reads", type=int, default=100000,
+                    help="reads of the BAM the decode / end-to-end legs run on (same generator and layout; 0 = skip those legs)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of N > 1)")
     ap.add_argument("--shared-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--gc-policy", default="pause", choices=["pause", "freeze", "none"],
@@ -45,7 +46,6 @@ def main():
     ap.add_argument("--mode", default="shard", choices=["shard", "samples"],
                     help="N > 1: 'shard' (default) = ONE sample, records sharded over the GPUs, exchange over RCCL (strong scaling); "
                          "'samples' = one independent sample per GPU, no collective on the data path (weak scaling, cohort use)")
-    ap.add_argument("--scan-variant", type=int, default=0, help="A/B only: coral_set_scan_variant (0 = library default)")
     a = ap.parse_args()
 
     import torch
@@ -69,9 +69,6 @@ def main():
     from coral_amd import infer_breakpoint_graph as ibg
     from coral_amd import sharding
 
-    if a.scan_variant:
-        from coral_amd import _lib
-        _lib.check(_lib.lib().coral_set_scan_variant(a.scan_variant), "coral_set_scan_variant")
     cfg = synth.named_config(a.config)
     if a.reads:
         cfg.n_reads = a.reads
@@ -123,11 +120,22 @@ def main():
         dt = float(tt.item())
     scan_ms = [e0.elapsed_time(e1) for e0, e1 in kernels.PROFILE["scan_ms"]]
     scan_ms_avg = sum(scan_ms) / max(1, len(scan_ms))
+    kernels.PROFILE.pop("scan_ms", None)
+    b_last = b
+    h2d_ms = measure_h2d(dr) if a.mode == "shard" else None          # every rank uploads its own shard: max over ranks
+    if world > 1 and h2d_ms is not None:
+        tt = torch.tensor([h2d_ms], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        h2d_ms = float(tt.item())
+    legs = bam_legs(a, rank, world, dev, work) if (a.bam_reads and a.mode == "shard") else None
+    b = b_last
 
     if rank == 0:
+        from coral_amd import _lib
         ms_per_step = dt / a.steps * 1e3
         value = n_reads_total * a.steps / dt
         achieved = alg_bytes_local / (scan_ms_avg * 1e-3) / 1e9 if scan_ms_avg > 0 else 0.0
+        scan_kernel = _lib.lib().coral_scan_kernel_name().decode()
         out = {
             "metric": "reads/sec through breakpoint-graph build", "value": value, "unit": "reads/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -139,12 +147,20 @@ def main():
                        "generate_s": round(gen_s, 2), "step_ms": step_ms, "gc_policy": a.gc_policy,
                        "parallelism": ("%d independent samples, one per GPU" % world) if (a.mode == "samples" and world > 1)
                        else "records sharded over %d GPU(s)" % world,
+                       # Amdahl: per step, only the per-record kernels (scan + coverage + point cover) shrink with more GPUs;
+                       # the order-sensitive host logic of rank 0 does not
+                       "serial_ms": round(ms_per_step - scan_ms_avg, 1),
                        "phase_ms_median": {k: round(sorted(p.get(k, 0.0) for p in phases)[len(phases) // 2] * 1e3, 1)
                                            for k in (phases[-1] if phases else {})}},
-            "roofline": {"bound": "hbm", "kernel": SCAN_KERNEL_NAME.get(a.scan_variant, "variant %d" % a.scan_variant), "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": pmc_traffic(cfg, world, SCAN_KERNEL_NAME.get(a.scan_variant)), "launch_ms": scan_ms_avg,
+            "roofline": {"bound": "hbm", "kernel": scan_kernel, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": pmc_traffic(cfg, world, scan_kernel), "launch_ms": scan_ms_avg,
                          "algorithmic_bytes_per_launch": int(alg_bytes_local)},
         }
+        if h2d_ms is not None:
+            out["h2d_ms"] = round(h2d_ms, 1)
+            out["value_incl_h2d"] = n_reads_total / (ms_per_step * 1e-3 + h2d_ms * 1e-3)
+        if legs:
+            out.update(legs)
         if a.cpu_sample and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.config, min(a.cpu_sample, cfg.n_reads), work)
         print(json.dumps(out), flush=True)
@@ -154,11 +170,85 @@ def main():
     shutil.rmtree(work, ignore_errors=True)
 
 
+def measure_h2d(dr):
+    """Pinned host -> HBM time of this rank's resident arrays (what a loader pays once per sample, outside `value`): the
+    arrays are streamed through a 256 MiB pinned staging buffer, chunk by chunk, into the very tensors they came from."""
+    import torch
+    staging = torch.empty(256 << 20, dtype=torch.uint8, pin_memory=True)
+    total_ms = 0.0
+    for t in (dr.cigar, dr.cigar_off, dr.tid, dr.pos, dr.end, dr.flagmq, dr.n_cigar):
+        flat = t.view(-1).view(torch.uint8)
+        for a in range(0, flat.numel(), staging.numel()):
+            n = min(staging.numel(), flat.numel() - a)
+            staging[:n].copy_(flat[a:a + n])                      # fill the staging buffer (not timed)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            flat[a:a + n].copy_(staging[:n], non_blocking=True)
+            e1.record()
+            e1.synchronize()
+            total_ms += e0.elapsed_time(e1)
+    return total_ms
+
+
+def bam_legs(a, rank, world, dev, work):
+    """`decode` and `end_to_end` on a real BAM file of --bam-reads reads of the same workload (writing the full 2 M-read file
+    would take minutes and ~20 GB; the cap is stated in the output).  N > 1: every rank decodes and uploads only its byte
+    range of the file; the end-to-end time is barrier to barrier."""
+    import torch
+    import torch.distributed as dist
+    from coral_amd import bam, sharding, synth
+    cfg = synth.scaled_config(a.config, min(a.bam_reads, synth.named_config(a.config).n_reads))
+    shared = os.path.join("/tmp", "coral_bench_bam_%s" % os.environ.get("MASTER_PORT", str(os.getpid())))
+    path = os.path.join(shared, "input.bam")
+    cn, seeds = os.path.join(shared, "cn.bed"), os.path.join(shared, "seeds.bed")
+    out = {}
+    if rank == 0:
+        os.makedirs(shared, exist_ok=True)
+        rec = synth.generate(cfg, dev, chunk_pieces=200000)
+        synth.write_cn_bed(cfg, cn)
+        synth.write_seed_bed(cfg, seeds)
+        t0 = time.perf_counter()
+        bam.write_bam_native(rec.to("cpu"), path, seed=1)
+        write_s = time.perf_counter() - t0
+        n_records = rec.n
+        del rec
+        size = os.path.getsize(path)
+        t0 = time.perf_counter()
+        whole = bam.decode_bam(path)
+        dec_s = time.perf_counter() - t0
+        st = dict(bam.LAST_DECODE)
+        assert whole.n == n_records
+        del whole
+        out["decode"] = {"reads_per_s": cfg.n_reads / dec_s, "threads": st["threads"], "GB_per_s_compressed": size / dec_s / 1e9,
+                         "GB_per_s_inflated": st["uncompressed_bytes"] / dec_s / 1e9, "seconds": round(dec_s, 2),
+                         "bam": "%d reads (%d records) of %s, %.2f GB BGZF, written in %.1f s; one process, whole file" % (
+                             cfg.n_reads, n_records, a.config, size / 1e9, write_s)}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dr = sharding.load_bam_sharded(path, rank, world, dev)
+    t1 = time.perf_counter()
+    b = sharding.build_graph_sharded(dr, seeds, cn, os.path.join(shared, "e2e") if rank == 0 else None, gc_policy=a.gc_policy)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t2 = time.perf_counter()
+    if rank == 0:
+        out["end_to_end"] = {"reads_per_s": cfg.n_reads / (t2 - t0), "seconds": round(t2 - t0, 2), "load_s": round(t1 - t0, 2),
+                             "build_s": round(t2 - t1, 2), "n_gpus": world,
+                             "what": "BAM file -> decode (every rank its byte range, %d threads) -> HBM -> graph files; first build of "
+                                     "the process on these records (includes one-off warm-up of the build)" % dr.decode_stats["threads"]}
+        shutil.rmtree(shared, ignore_errors=True)
+    return out if rank == 0 else None
+
+
 def pmc_traffic(cfg, world, kernel):
-    """HBM bytes per scan launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json) when they
+    """HBM bytes per scan launch from the committed rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json) when they
     were taken on exactly this workload on one GPU; counters cannot be collected from inside this process -> else None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fp:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fp:
             p = json.load(fp)
         if world == 1 and p["workload"] == cfg.name and p["n_reads"] == cfg.n_reads and p["scan_kernel"] == kernel:
             return p["kernels"][p["scan_kernel"]]["hbm_bytes"]
@@ -184,7 +274,18 @@ def cpu_baseline(config, n_sample, work):
     t0 = time.perf_counter()
     O.reconstruct_graph(host, seeds, cn, os.path.join(work, "cpu"))
     dt = time.perf_counter() - t0
+    # the same from a BAM file: one decoder thread (the reference's pysam reads with one thread) + the same build
+    from coral_amd import bam
+    path = os.path.join(work, "cpu_sample.bam")
+    bam.write_bam_native(rec, path, seed=1)
+    t0 = time.perf_counter()
+    back = bam.decode_bam(path, n_threads=1)
+    t1 = time.perf_counter()
+    O.reconstruct_graph(HostRecords(back), seeds, cn, os.path.join(work, "cpu_e2e"))
+    t2 = time.perf_counter()
     return {"value": n_sample / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+            "end_to_end": {"reads_per_s": n_sample / (t2 - t0), "decode_s": round(t1 - t0, 2), "build_s": round(t2 - t1, 2),
+                           "what": "BAM file -> one-thread decode -> CPU oracle -> graph files"},
             "sample": "first %d reads of %s (same generator and seed), decoded records in host memory -> graph files, %.1f s; "
                       "single-threaded like the reference (host has %d cores)" % (n_sample, config, dt, os.cpu_count() or 0)}
 

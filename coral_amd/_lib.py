@@ -36,16 +36,11 @@ def lib():
     L.coral_last_error.restype = C.c_char_p
     P = C.c_void_p
     R = C.POINTER(coral_records_t)
-    L.coral_cigar_scan.argtypes = [R, C.c_int32, C.c_int32, P, P, P, P, P, P, C.c_uint32, P]
-    L.coral_time_cigar_scan.argtypes = [R, C.c_int32, C.c_int32, P, P, P, P, P, P, C.c_uint32, C.c_int32,
-                                        C.POINTER(C.c_float), P]
-    L.coral_segment_coverage.argtypes = [R, P, P, C.c_int32, P, P, P, P, P, P, P, P]
+    L.coral_cigar_scan.argtypes = [R, C.c_int32, C.c_int32, P, P, P, C.c_uint32, P]
+    L.coral_scan_kernel_name.restype = C.c_char_p
+    L.coral_segment_coverage.argtypes = [R, P, C.c_int32, P, P, P, P, P, P, P, P]
     L.coral_point_cover.argtypes = [R, C.c_int32, P, P, P, P, C.c_uint32, P]
     L.coral_read_counter.argtypes = [P, C.POINTER(C.c_uint32), P]
-    L.coral_set_scan_variant.argtypes = [C.c_int]
-    L.coral_set_scan_variant.restype = C.c_int
-    L.coral_time_stream_read.argtypes = [P, C.c_longlong, P, C.c_int, C.POINTER(C.c_float), P]
-    L.coral_time_stream_read.restype = C.c_int
     L.coral_first_seen_rows.argtypes = [C.c_int64, C.c_int32, P, P]
     L.coral_first_seen_rows.restype = C.c_int
     L.coral_bp_pair_table.argtypes = [C.c_int32, C.c_int32, P, P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P]
@@ -100,10 +95,14 @@ def lib():
     L.coral_bam_decode_fill.argtypes = [C.c_void_p] + [P] * 20
     L.coral_bam_decode_close.argtypes = [C.c_void_p]
     L.coral_bam_last_error.restype = C.c_char_p
-    for name in ("coral_bam_decode_open", "coral_bam_decode_sizes", "coral_bam_decode_fill", "coral_bam_decode_close"):
+    L.coral_bam_decode_range.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.coral_bam_decode_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    L.coral_bam_write.argtypes = [C.c_char_p, C.c_int64] + [P] * 9 + [P, P, P, P, P, C.c_int64, P, P, P, C.c_int32, P, P, C.c_uint32,
+                                                                        C.c_int32, C.c_int32]
+    for name in ("coral_bam_decode_open", "coral_bam_decode_sizes", "coral_bam_decode_fill", "coral_bam_decode_close",
+                 "coral_bam_decode_range", "coral_bam_decode_stats", "coral_bam_write"):
         getattr(L, name).restype = C.c_int
-    for name in ("coral_cigar_scan", "coral_time_cigar_scan", "coral_segment_coverage", "coral_point_cover",
-                 "coral_read_counter"):
+    for name in ("coral_cigar_scan", "coral_segment_coverage", "coral_point_cover", "coral_read_counter"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

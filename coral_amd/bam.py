@@ -20,14 +20,37 @@ from . import _lib
 from .synth import Records, hash_u32, S_SEQ, sa_entry_string
 
 
-def decode_bam(path: str, n_threads: Optional[int] = None) -> Records:
+def default_threads() -> int:
+    """Decoder threads: the CPUs this process may actually use (affinity mask and, in a container, the cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(64, n))
+
+
+LAST_DECODE = {}      # statistics of the last decode_bam call (bench.py): seconds, compressed / uncompressed bytes, threads
+
+
+def decode_bam(path: str, n_threads: Optional[int] = None, rank: int = 0, world: int = 1) -> Records:
+    """Decode the BAM file (or, with ``world`` > 1, the ``rank``-th of ``world`` byte ranges of it: one process per GPU, every
+    rank inflates and parses only its share; consecutive ranges neither drop nor repeat a record).  Read-name ids are local
+    to the returned records."""
     L = _lib.lib()
     if n_threads is None:
-        n_threads = max(1, min(16, os.cpu_count() or 1))
+        n_threads = default_threads()
     h = C.c_void_p()
-    rc = L.coral_bam_decode_open(path.encode(), n_threads, C.byref(h))
+    rc = L.coral_bam_decode_range(path.encode(), n_threads, rank, world, C.byref(h))
     if rc != 0:
-        raise _lib.CoralHipError("coral_bam_decode_open(%s) failed (%d): %s" % (path, rc, L.coral_bam_last_error().decode()))
+        raise _lib.CoralHipError("coral_bam_decode(%s) failed (%d): %s" % (path, rc, L.coral_bam_last_error().decode()))
+    st, secs = (C.c_int64 * 3)(), C.c_double(0.0)
+    L.coral_bam_decode_stats(h, st, C.byref(secs))
+    LAST_DECODE.clear()
+    LAST_DECODE.update(seconds=float(secs.value), compressed_bytes=int(st[0]), uncompressed_bytes=int(st[1]), blocks=int(st[2]),
+                       threads=int(n_threads))
     try:
         sz = (C.c_int64 * 8)()
         _lib.check(L.coral_bam_decode_sizes(h, sz), "coral_bam_decode_sizes")
@@ -59,6 +82,30 @@ def decode_bam(path: str, n_threads: Optional[int] = None) -> Records:
                    cigar=t(cigar.view(np.int32)), sa_off=t(sa_off), sa=t(sa), sa_nm=t(sa_nm), nonacgt_rec=t(na_rec),
                    nonacgt_pos=t(na_pos), n_names=nnames, name_gid=None, names=[x.decode() for x in names],
                    header_chroms=[x.decode() for x in refs], header_lens=[int(x) for x in ref_lens])
+
+
+def write_bam_native(rec: Records, path: str, seed: int = 0, level: int = 1, n_threads: Optional[int] = None) -> None:
+    """Serialise ``rec`` as a coordinate-sorted BAM with the native multi-threaded writer (coral_bam_write): what benchmarks
+    and the larger tests use — same content rules as ``write_bam`` (deterministic ACGT with N at the listed positions, QUAL
+    absent, NM / SA / CG tags), different (hash-made) bases."""
+    L = _lib.lib()
+    g = lambda x, dt: np.ascontiguousarray(x.cpu().numpy(), dtype=dt)
+    i32 = lambda k: g(getattr(rec, k), np.int32)
+    cols = [i32(k) for k in ("tid", "pos", "flag", "mapq", "qlen", "has_seq", "nm", "name_id", "n_cigar")]
+    cigar_off, cigar = g(rec.cigar_off, np.int64), g(rec.cigar, np.int32).view(np.uint32)
+    sa_off, sa, sa_nm = g(rec.sa_off, np.int64), g(rec.sa, np.int32), g(rec.sa_nm, np.int32)
+    na_rec, na_pos = g(rec.nonacgt_rec, np.int64), g(rec.nonacgt_pos, np.int32)
+    names = [s.encode() for s in rec.materialise_names()]
+    name_arr = (C.c_char_p * max(len(names), 1))(*names)
+    refs = [c.encode() for c in rec.header_chroms]
+    ref_arr = (C.c_char_p * max(len(refs), 1))(*refs)
+    ref_lens = np.ascontiguousarray(rec.header_lens, dtype=np.int32)
+    ptr = lambda a: a.ctypes.data
+    rc = L.coral_bam_write(path.encode(), rec.n, *[ptr(c) for c in cols], ptr(cigar_off), ptr(cigar), ptr(sa_off), ptr(sa), ptr(sa_nm),
+                           len(na_rec), ptr(na_rec), ptr(na_pos), name_arr, len(refs), ref_arr, ptr(ref_lens), seed, level,
+                           n_threads or default_threads())
+    if rc != 0:
+        raise _lib.CoralHipError("coral_bam_write(%s) failed (%d): %s" % (path, rc, L.coral_bam_last_error().decode()))
 
 
 # ----------------------------------------------------------------------------------------------

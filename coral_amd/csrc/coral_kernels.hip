@@ -35,6 +35,8 @@ static int hip_err(hipError_t e, const char *what) {
 
 extern "C" const char *coral_version(void) { return "coral_hip 0.1 (gfx950)"; }
 extern "C" const char *coral_last_error(void) { return g_err; }
+// name of the kernel coral_cigar_scan launches, as rocprofv3 prints it (bench.py puts it next to the roofline figures)
+extern "C" const char *coral_scan_kernel_name(void);
 
 // ---------------------------------------------------------------------------------------------
 // wave helpers
@@ -48,141 +50,18 @@ __device__ __forceinline__ int wave_incl_scan_add(int x, int lane) {
     return x;
 }
 
-__device__ __forceinline__ int wave_reduce_add(int x) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d);
-    return x;
-}
-
 __device__ __forceinline__ long long wave_reduce_add64(long long x) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d);
     return x;
 }
 
-__device__ __forceinline__ int wave_reduce_min(int x) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) x = min(x, __shfl_xor(x, d));
-    return x;
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1  cigar_scan — one wave per record, 256 ops (1 KiB) per wave-iteration, next chunk prefetched
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan(
-    long long n_rec, const int32_t *__restrict__ pos, const int32_t *__restrict__ flagmq,
-    const int32_t *__restrict__ n_cigar, const int64_t *__restrict__ cigar_off,
-    const uint32_t *__restrict__ cigar, int min_gap, int min_mapq, int32_t *__restrict__ mbases,
-    int32_t *__restrict__ qinfer, int32_t *__restrict__ blk_first, int32_t *__restrict__ blk_last,
-    int32_t *__restrict__ gaps, uint32_t *__restrict__ gap_count, uint32_t gap_cap) {
-    const int lane = threadIdx.x & 63;
-    const long long wave = (long long)blockIdx.x * (SCAN_BLOCK / WAVE) + (threadIdx.x >> 6);
-    const long long nwaves = (long long)gridDim.x * (SCAN_BLOCK / WAVE);
-    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const cquad_t pad = {OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD};
-
-    for (long long r = wave; r < n_rec; r += nwaves) {
-        const int n = n_cigar[r];
-        const int nq = (n + 3) >> 2;
-        const cquad_t *__restrict__ q = reinterpret_cast<const cquad_t *>(cigar + cigar_off[r]);
-        const int p0 = pos[r];
-        const bool gaps_on = ((flagmq[r] >> 16) & 0xff) >= min_mapq;
-
-        int carry_ref = 0;   // reference bases consumed by earlier chunks
-        int carry_end = 0;   // end (relative, >= 1) of the last aligned block seen so far; 0 = none
-        int msum = 0, qsum = 0, first = 0x7fffffff;
-
-        cquad_t cur = pad;
-        if (lane < nq) cur = q[lane];
-        for (int c = 0; c < nq; c += WAVE) {
-            cquad_t nxt = pad;
-            if (c + WAVE + lane < nq) nxt = q[c + WAVE + lane];   // prefetch the next KiB
-
-            const uint32_t v[4] = {cur.x, cur.y, cur.z, cur.w};
-            int len[4], adv[4];
-            bool aln[4];
-            int tot = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t op = v[k] & 15u;
-                len[k] = (int)(v[k] >> 4);
-                adv[k] = ((MASK_REF >> op) & 1u) ? len[k] : 0;
-                aln[k] = (MASK_ALN >> op) & 1u;
-                qsum += ((MASK_QRY >> op) & 1u) ? len[k] : 0;
-                tot += adv[k];
-            }
-            const int incl = wave_incl_scan_add(tot, lane);
-            int ref = carry_ref + incl - tot;      // reference offset of this lane's first op
-            // end of the last aligned block inside this lane (0 = none)
-            int lane_end = 0;
-            {
-                int rr = ref;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (aln[k]) lane_end = rr + len[k];
-                    rr += adv[k];
-                }
-            }
-            // previous aligned block end as seen by this lane's first aligned op
-            const unsigned long long has = __ballot(lane_end != 0);
-            const unsigned long long lower = has & below;
-            const int src = lower ? (63 - __clzll(lower)) : 0;
-            const int from_lane = __shfl(lane_end, src);
-            int prev = lower ? from_lane : carry_end;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (aln[k]) {
-                    if (prev > 0 && gaps_on && ref - prev > min_gap) {
-                        const uint32_t slot = atomicAdd(gap_count, 1u);
-                        if (slot < gap_cap) {
-                            int4 row = make_int4((int)r, (c + lane) * 4 + k, p0 + prev, p0 + ref);
-                            reinterpret_cast<int4 *>(gaps)[slot] = row;
-                        }
-                    }
-                    first = min(first, ref);
-                    prev = ref + len[k];
-                    msum += len[k];
-                }
-                ref += adv[k];
-            }
-            carry_ref += __shfl(incl, 63);
-            carry_end = __shfl(prev, 63);
-            cur = nxt;
-        }
-        msum = wave_reduce_add(msum);
-        qsum = wave_reduce_add(qsum);
-        first = wave_reduce_min(first);
-        if (lane == 0) {
-            mbases[r] = msum;
-            qinfer[r] = qsum;
-            blk_first[r] = (carry_end > 0) ? p0 + first : -1;
-            blk_last[r] = (carry_end > 0) ? p0 + carry_end : -1;
-        }
-    }
-}
-
-__device__ __forceinline__ cquad_t pad_or(const cquad_t *__restrict__ q, long long i, long long n) {
-    cquad_t v = {0u, 0u, 0u, 0u};
-    if (i < n) v = q[i];
-    return v;
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1  k_cigar_scan_v2 — the production scan kernel (default instantiation <8, false, true, 8>: 8 KiB per wave in flight,
-// conservative gap filter, tiles of 8 consecutive records per wave).  Same contract as k_cigar_scan above, restructured
-// for the memory system:
-//   * the (record, chunk) sequence of a wave is flattened and a whole batch of chunks is loaded ahead of the arithmetic,
-//     across record boundaries, so a wave never idles on the metadata -> first-quad load chain at the start of a record;
-//   * record metadata is wave-uniform and fetched with scalar loads, one record ahead of its use;
-//   * the wave scan / reductions use DPP row shifts + row broadcasts (6 VALU ops, no LDS crossbar), and
-//     wave-uniform values are taken with v_readlane instead of a shuffle;
-//   * FILTER / TILE / FULLCHUNK: see the template below and profiles/r01_scan_variants.md.
-// ---------------------------------------------------------------------------------------------
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_zero(int src) {
     return __builtin_amdgcn_update_dpp(0, src, CTRL, ROW_MASK, 0xf, true);
 }
 
+// inclusive add-scan over the 64 lanes: 4 row shifts + 2 row broadcasts (no LDS crossbar)
 __device__ __forceinline__ int wave_incl_scan_add_dpp(int x) {
     x += dpp_zero<0x111, 0xf>(x);   // row_shr:1
     x += dpp_zero<0x112, 0xf>(x);   // row_shr:2
@@ -197,332 +76,268 @@ __device__ __forceinline__ int wave_sum_dpp(int x) {
     return __builtin_amdgcn_readlane(wave_incl_scan_add_dpp(x), 63);
 }
 
-// BATCH = chunks (KiB) a wave loads back to back: BATCH KiB per wave in flight while the previous batch is processed
-// FILTER = true (variant 7): a chunk first passes a cheap, conservative "can this chunk hold a large gap at all?" test and
-// only the chunks that fail it run the exact gap search (max-scan over the wave + per-op distance tests).  A gap is the
-// sum of the reference-advancing NON-aligned ops (D, N) between two consecutive aligned ops.  With G(l) = that sum over
-// the four ops of lane l, a lane is flagged when it holds real ops but no aligned op, or when G(l) > min_gap / 2.  If no
-// lane of a chunk is flagged and the last lane of the previous chunk of the record was not flagged either, then two
-// consecutive aligned ops are at most one lane apart (a lane in between would have no aligned op), so every gap that ends
-// in this chunk is <= G(l) + G(l + 1) <= min_gap: nothing to report, and the running "end of the last aligned block" is
-// simply the one of the highest lane holding an aligned op.  Exact for every input; CIGARs of real reads trip the filter
-// only around actual large deletions and at the (padded) end of a record.
-// TILE > 1: a wave takes TILE consecutive records at a time (tiles interleaved over the waves) instead of every
-// nwaves-th record, so its loads and its scalar metadata reads walk contiguous memory.
-template <int BATCH, bool LIGHT = false, bool FILTER = false, int TILE = 1, bool FULLCHUNK = false>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v2(
-    long long n_rec, const int32_t *__restrict__ pos, const int32_t *__restrict__ flagmq,
-    const int32_t *__restrict__ n_cigar, const int64_t *__restrict__ cigar_off,
-    const uint32_t *__restrict__ cigar, int min_gap, int min_mapq, int32_t *__restrict__ mbases,
-    int32_t *__restrict__ qinfer, int32_t *__restrict__ blk_first, int32_t *__restrict__ blk_last,
-    int32_t *__restrict__ gaps, uint32_t *__restrict__ gap_count, uint32_t gap_cap) {
-    const int lane = threadIdx.x & 63;
-    const long long wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (SCAN_BLOCK / WAVE) + (threadIdx.x >> 6)));
-    const long long nwaves = (long long)gridDim.x * (SCAN_BLOCK / WAVE);
-    const cquad_t pad = {OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD};
-    // per-op classes, 4 bits per BAM op code: bit0 advances the reference (M D N = X), bit1 aligned block (M = X),
-    // bit2 counts towards infer_read_length (M I S H = X); op 15 (padding) and the unused codes are 0.
-    const unsigned long long OPCLASS = 0x0000000770441147ull;
+// ---------------------------------------------------------------------------------------------
+// K1  k_cigar_scan_v3 — the fused CIGAR pass (production kernel of coral_cigar_scan).
+//
+// Per alignment record: Σ aligned bases, infer_read_length, first / last aligned block, and every gap > min_gap between
+// consecutive aligned blocks (the get_blocks() walk of /root/reference/src/infer_breakpoint_graph.py:750-762 plus the
+// per-record sums count_coverage / infer_read_length need, ibg:131, :1031-1034).  HBM-bound: 4 bytes per CIGAR op, read once.
+//
+// Structure (what round 1's measurements asked for: profiles/r01_scan_variants.md, profiles/r02_scan.md):
+//   * FLAT STREAM, BALANCED.  The op array of all records is one contiguous stream of 16-byte quads (records are padded to whole
+//     quads).  Wave w owns the records whose first quad falls into the w-th of n_waves equal slices of that stream (found with a
+//     64-ary cooperative search of cigar_off), so every wave streams the same number of bytes (± one record), all waves are
+//     resident at once (grid = what fits the chip) and nothing is left for a second round of workgroups.
+//   * LDS RING FED BY LDS-DMA.  Each wave keeps RING KiB in flight with global_load_lds_dwordx4 (1 KiB per instruction, no VGPR
+//     destination): full, unmasked, 128-byte-aligned loads that ignore record boundaries; one counted s_waitcnt vmcnt(RING - 1)
+//     per chunk retires the oldest slot, the lane reads its quad with one ds_read_b128, and the slot is refilled at once.  Data
+//     costs no registers, so occupancy is set by LDS (RING KiB per wave), not by a 64-VGPR double buffer.
+//   * RECORD BOUNDARIES IN THE ARITHMETIC.  A chunk that lies inside one record (6 of 7 at 20 kb reads) takes the single-piece
+//     path; otherwise it is processed once per record piece with the other lanes masked to padding (op 15 consumes nothing).
+//   * The arithmetic per piece is round 1's: branch-free class lookup (v_bfe_i32 with the op word as bit offset), DPP add-scan
+//     for the reference offsets, and the conservative gap filter — only pieces that can hold a gap > min_gap run the exact
+//     max-scan + distance tests (see `scan_piece`).
+//   * SUMMARIES LEAVE IN 1 KiB STORES.  The four per-record results are one 16-byte row; rows are parked in LDS and written 64
+//     at a time as one coalesced store (round 1 wrote four scattered 4-byte words per record: 7.3 x write amplification).
+// ---------------------------------------------------------------------------------------------
+struct ScanState {
+    int carry_ref, carry_end, msum, qsum, first;
+    bool tail_flagged;
+};
 
-    // fetch cursor: (record, first chunk of the batch); runs one batch ahead of the arithmetic, across records.
-    // Record metadata is wave-uniform (scalar loads) and requested ONE RECORD AHEAD of its use, so the wave never
-    // stalls on the metadata -> first-quad dependency when it moves to its next record.
-    auto next_rec = [&](long long r) -> long long {      // the record this wave handles after record r
-        if (TILE == 1) return r + nwaves;
-        return ((r + 1) % TILE != 0) ? r + 1 : r + 1 + (nwaves - 1) * TILE;
-    };
-    long long fr = wave * TILE;
-    int fc = 0, fnq = 0;
-    const cquad_t *__restrict__ fq = reinterpret_cast<const cquad_t *>(cigar);
-    int f_nn = 0;            // n_cigar / cigar_off of record fr + nwaves (requested earlier)
-    long long f_noff = 0;
-    const long long last_rec = n_rec - 1;      // n_rec >= 1 (checked by the launcher)
-    auto f_request = [&](long long r) {        // unconditional scalar loads (clamped): no select on the loaded value
-        const long long rr = r < n_rec ? r : last_rec;
-        f_nn = n_cigar[rr];
-        f_noff = cigar_off[rr];
-    };
-    auto f_meta = [&]() {      // switch to record fr using the values requested earlier, request the one after
-        fc = 0;
-        fnq = fr < n_rec ? (f_nn + 3) >> 2 : 0;
-        fq = reinterpret_cast<const cquad_t *>(cigar + f_noff);
-        f_request(next_rec(fr));
-    };
-    auto f_fetch = [&](cquad_t (&dst)[BATCH]) {
+// One piece = the lanes of one chunk that belong to the current record (the others hold OP_PAD_QUAD).  `quad0` = index within
+// the record of lane 0's quad (may be negative for lanes in front of the record; those lanes are padding).
+//
+// Conservative gap filter: a gap is the sum of the reference-advancing NON-aligned ops (D, N) between two consecutive aligned
+// ops.  With G(l) = that sum over the four ops of lane l, a lane is flagged when it holds real ops but no aligned op, or when
+// G(l) > min_gap / 2.  If no lane of the piece is flagged and the last lane of the record's previous piece was not flagged
+// either, two consecutive aligned ops are at most one lane apart, so every gap that ends in this piece is
+// <= G(l) + G(l + 1) <= min_gap: nothing to report, and the running "end of the last aligned block" is the one of the highest
+// lane holding an aligned op.  Exact for every input (tests/test_gpu_kernels.py: adversarial CIGAR set).
+__device__ __forceinline__ void scan_piece(const cquad_t b0, const int lane, ScanState &st, const bool gaps_on, const int min_gap,
+                                           const int half_gap, const int rec, const int quad0, const int p0,
+                                           int32_t *__restrict__ gaps, uint32_t *__restrict__ gap_count, const uint32_t gap_cap) {
+    int len[4], adv[4], aend[4], ref[4];
+    int fal[4];                          // 0 / -1 per op, "is an aligned block"
+    int tot = 0, asum = 0;
 #pragma unroll
-        for (int j = 0; j < BATCH; ++j) {
-            if (FULLCHUNK && fc + (j + 1) * WAVE <= fnq) {          // (wave-uniform) whole chunk inside the record:
-                const cquad_t *__restrict__ base = fq + fc + j * WAVE;      // SGPR base + lane offset, no masking, no padding fill
-                dst[j] = base[lane];
-            } else {
-                dst[j] = pad;
-                if (fc + j * WAVE + lane < fnq) dst[j] = fq[fc + j * WAVE + lane];     // exec-masked dwordx4
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t w = b0[k];
+        len[k] = (int)(w >> 4);
+        // v_bfe_i32 takes its bit offset from the low 5 bits of the operand: op code + 16 * (length & 1); the class masks are
+        // replicated into both halves, so the op word itself is the offset
+        const int fr_ = __builtin_amdgcn_sbfe((int)(MASK_REF * 0x10001u), w, 1u);
+        const int fa_ = __builtin_amdgcn_sbfe((int)(MASK_ALN * 0x10001u), w, 1u);
+        const int fq_ = __builtin_amdgcn_sbfe((int)(MASK_QRY * 0x10001u), w, 1u);
+        adv[k] = len[k] & fr_;
+        aend[k] = len[k] & fa_;
+        fal[k] = fa_;
+        st.qsum += len[k] & fq_;
+        asum += aend[k];
+        tot += adv[k];
+    }
+    st.msum += asum;
+    const int incl = wave_incl_scan_add_dpp(tot);
+    ref[0] = st.carry_ref + incl - tot;
+    const int m3 = fal[3], m2 = m3 | fal[2], m1 = m2 | fal[1], m0 = m1 | fal[0];
+    const unsigned long long flagged = (__ballot(m0 == 0) & __ballot(b0[0] != OP_PAD_QUAD)) | __ballot(tot - asum > half_gap);
+    const bool exact = flagged != 0ull || st.tail_flagged;
+    st.tail_flagged = (flagged >> 63) != 0ull;
+    if (!exact) {
+        const unsigned long long has = __ballot(m0 != 0);   // 0 only for a piece without any aligned op (all padding)
+        if (has != 0ull) {
+            if (st.carry_end == 0) {        // (wave-uniform) the record's first block starts in this piece:
+                // reference-advancing ops in front of the lane's first aligned op (masks only, no selects)
+                const int n0 = ~fal[0], n1 = n0 & ~fal[1], n2 = n1 & ~fal[2];
+                const int lf = ref[0] + (adv[0] & n0) + (adv[1] & n1) + (adv[2] & n2);
+                st.first = __builtin_amdgcn_readlane(lf, (int)__builtin_ctzll(has));
+            }
+            // end of the last aligned block of the lane, relative to the lane's first op
+            const int off_end = adv[0] + (adv[1] & m1) + (adv[2] & m2) + (adv[3] & m3);
+            st.carry_end = __builtin_amdgcn_readlane(ref[0] + off_end, 63 - (int)__builtin_clzll(has));
+        }
+    } else {
+        const bool aln[4] = {fal[0] != 0, fal[1] != 0, fal[2] != 0, fal[3] != 0};
+        ref[1] = ref[0] + adv[0];
+        ref[2] = ref[1] + adv[1];
+        ref[3] = ref[2] + adv[2];
+        // running "end of the last aligned block" inside the lane (0 = none yet)
+        int run[4];
+        run[0] = aln[0] ? ref[0] + aend[0] : 0;
+        run[1] = aln[1] ? ref[1] + aend[1] : run[0];
+        run[2] = aln[2] ? ref[2] + aend[2] : run[1];
+        run[3] = aln[3] ? ref[3] + aend[3] : run[2];
+        // previous block end seen by this lane = max over earlier lanes (ends never decrease), else the carry
+        int mx = run[3];
+        mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x111, 0xf, 0xf, true));
+        mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x112, 0xf, 0xf, true));
+        mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x114, 0xf, 0xf, true));
+        mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x118, 0xf, 0xf, true));
+        mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x142, 0xa, 0xf, true));
+        mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x143, 0xc, 0xf, true));
+        const int shifted = __builtin_amdgcn_update_dpp(st.carry_end, mx, 0x138, 0xf, 0xf, false);   // wave_shr:1
+        const int prev_in = max(shifted, st.carry_end);
+        if (st.carry_end == 0) {                    // (wave-uniform) still looking for the record's first block
+            const unsigned long long has = __ballot(run[3] != 0);
+            if (has != 0ull) {
+                int lf = ref[3];
+                lf = aln[2] ? ref[2] : lf;
+                lf = aln[1] ? ref[1] : lf;
+                lf = aln[0] ? ref[0] : lf;
+                st.first = __builtin_amdgcn_readlane(lf, (int)__builtin_ctzll(has));
             }
         }
-    };
-    auto f_step = [&]() {
-        fc += BATCH * WAVE;
-        if (fc >= fnq) {
-            fr = next_rec(fr);
-            f_meta();
-        }
-    };
-    // process cursor (its metadata is requested one record ahead as well)
-    long long pr = wave * TILE;
-    int pc = 0, pnq = 0, p0 = 0;
-    bool gaps_on = false;
-    int p_nn = 0, p_npos = 0, p_nfm = 0;
-    auto p_request = [&](long long r) {
-        const long long rr = r < n_rec ? r : last_rec;
-        p_nn = n_cigar[rr];
-        p_npos = pos[rr];
-        p_nfm = flagmq[rr];
-    };
-    auto p_meta = [&]() {
-        pc = 0;
-        pnq = (p_nn + 3) >> 2;
-        p0 = p_npos;
-        gaps_on = ((p_nfm >> 16) & 0xff) >= min_mapq;
-        p_request(next_rec(pr));
-    };
-    f_request(fr);
-    p_request(pr);
-    f_meta();
-    p_meta();
-    cquad_t cur[BATCH], nxt[BATCH];
-    f_fetch(cur);
-    f_step();
-
-    int carry_ref = 0, carry_end = 0, msum = 0, qsum = 0, first = 0;
-    bool tail_flagged = false;                  // FILTER: last lane of the record's previous chunk was flagged
-    const int half_gap = min_gap >> 1;
-    while (pr < n_rec) {
-        // Touch the current batch: the compiler places its wait for these registers HERE, i.e. before the next
-        // batch is issued, so the next 4 KiB stay in flight for the whole of this batch's arithmetic.
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) asm volatile("" : "+v"(cur[j]));
-        f_fetch(nxt);
-        f_step();
-
-        if (LIGHT) {      // diagnostic build: same cursors and loads, no arithmetic (isolates the access pattern)
-#pragma unroll
-            for (int j = 0; j < BATCH; ++j) msum += (int)(cur[j][0] ^ cur[j][1] ^ cur[j][2] ^ cur[j][3]);
-        } else
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) {
-            if (j > 0 && pc + j * WAVE >= pnq) break;        // wave-uniform
-            const cquad_t b0 = cur[j];
-            // ---- branch-free decode of the lane's four ops
-            int len[4], adv[4], aend[4], ref[4];
-            int fal[4];                          // 0 / -1 per op, "is an aligned block"
-            int tot = 0, asum = 0;
+        // gap test, branch-free: distance from the previous block end (a huge "previous" when there is none)
+        const int none = 0x3fffffff;
+        const int pin = prev_in == 0 ? none : prev_in;
+        const int pv1 = run[0] ? run[0] : pin, pv2 = run[1] ? run[1] : pin, pv3 = run[2] ? run[2] : pin;
+        const bool h0 = aln[0] && (ref[0] - pin > min_gap);
+        const bool h1 = aln[1] && (ref[1] - pv1 > min_gap);
+        const bool h2 = aln[2] && (ref[2] - pv2 > min_gap);
+        const bool h3 = aln[3] && (ref[3] - pv3 > min_gap);
+        if (gaps_on && __ballot(h0 | h1 | h2 | h3) != 0ull) {          // rare: some lane holds a large gap
+            const int pv[4] = {pin, pv1, pv2, pv3};
+            const bool hit[4] = {h0, h1, h2, h3};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint32_t w = b0[k];
-                len[k] = (int)(w >> 4);
-                if (FILTER) {
-                    // v_bfe_i32 takes its bit offset from the low 5 bits of the operand: op code + 16 * (length & 1);
-                    // the class masks are replicated into both halves, so the op word itself is the offset.
-                    const int fr_ = __builtin_amdgcn_sbfe((int)(MASK_REF * 0x10001u), w, 1u);
-                    const int fa_ = __builtin_amdgcn_sbfe((int)(MASK_ALN * 0x10001u), w, 1u);
-                    const int fq_ = __builtin_amdgcn_sbfe((int)(MASK_QRY * 0x10001u), w, 1u);
-                    adv[k] = len[k] & fr_;
-                    aend[k] = len[k] & fa_;
-                    fal[k] = fa_;
-                    qsum += len[k] & fq_;
-                } else {
-                    const uint32_t f = (uint32_t)(OPCLASS >> ((w << 2) & 60u));
-                    adv[k] = len[k] & -(int)(f & 1u);
-                    aend[k] = len[k] & -(int)((f >> 1) & 1u);
-                    fal[k] = -(int)((f >> 1) & 1u);
-                    qsum += len[k] & -(int)((f >> 2) & 1u);
-                }
-                asum += aend[k];
-                tot += adv[k];
-            }
-            msum += asum;
-            const int incl = wave_incl_scan_add_dpp(tot);
-            ref[0] = carry_ref + incl - tot;
-            bool exact = true;
-            if (FILTER) {
-                const int m3 = fal[3], m2 = m3 | fal[2], m1 = m2 | fal[1], m0 = m1 | fal[0];
-                const unsigned long long flagged = (__ballot(m0 == 0) & __ballot(b0[0] != OP_PAD_QUAD)) | __ballot(tot - asum > half_gap);
-                exact = flagged != 0ull || tail_flagged;
-                tail_flagged = (flagged >> 63) != 0ull;
-                if (!exact) {
-                    const unsigned long long has = __ballot(m0 != 0);   // 0 only for a record without any op (all padding)
-                    if (has != 0ull) {
-                        if (carry_end == 0) {        // (wave-uniform) the record's first block starts in this chunk:
-                            // reference-advancing ops in front of the lane's first aligned op (masks only, no selects)
-                            const int n0 = ~fal[0], n1 = n0 & ~fal[1], n2 = n1 & ~fal[2];
-                            const int lf = ref[0] + (adv[0] & n0) + (adv[1] & n1) + (adv[2] & n2);
-                            first = __builtin_amdgcn_readlane(lf, (int)__builtin_ctzll(has));
-                        }
-                        // end of the last aligned block of the lane, relative to the lane's first op
-                        const int off_end = adv[0] + (adv[1] & m1) + (adv[2] & m2) + (adv[3] & m3);
-                        carry_end = __builtin_amdgcn_readlane(ref[0] + off_end, 63 - (int)__builtin_clzll(has));
+                if (hit[k]) {
+                    const uint32_t slot = atomicAdd(gap_count, 1u);
+                    if (slot < gap_cap) {
+                        int4 row = make_int4(rec, (quad0 + lane) * 4 + k, p0 + pv[k], p0 + ref[k]);
+                        reinterpret_cast<int4 *>(gaps)[slot] = row;
                     }
                 }
             }
-            if (exact) {
-            const bool aln[4] = {fal[0] != 0, fal[1] != 0, fal[2] != 0, fal[3] != 0};
-            ref[1] = ref[0] + adv[0];
-            ref[2] = ref[1] + adv[1];
-            ref[3] = ref[2] + adv[2];
-            // running "end of the last aligned block" inside the lane (0 = none yet)
-            int run[4];
-            run[0] = aln[0] ? ref[0] + aend[0] : 0;
-            run[1] = aln[1] ? ref[1] + aend[1] : run[0];
-            run[2] = aln[2] ? ref[2] + aend[2] : run[1];
-            run[3] = aln[3] ? ref[3] + aend[3] : run[2];
-            // previous block end seen by this lane = max over earlier lanes (ends never decrease), else the carry
-            int mx = run[3];
-            mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x111, 0xf, 0xf, true));
-            mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x112, 0xf, 0xf, true));
-            mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x114, 0xf, 0xf, true));
-            mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x118, 0xf, 0xf, true));
-            mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x142, 0xa, 0xf, true));
-            mx = max(mx, __builtin_amdgcn_update_dpp(0, mx, 0x143, 0xc, 0xf, true));
-            const int shifted = __builtin_amdgcn_update_dpp(carry_end, mx, 0x138, 0xf, 0xf, false);   // wave_shr:1
-            const int prev_in = max(shifted, carry_end);
-            if (carry_end == 0) {                    // (wave-uniform) still looking for the record's first block
-                const unsigned long long has = __ballot(run[3] != 0);
-                if (has != 0ull) {
-                    int lf = ref[3];
-                    lf = aln[2] ? ref[2] : lf;
-                    lf = aln[1] ? ref[1] : lf;
-                    lf = aln[0] ? ref[0] : lf;
-                    first = __builtin_amdgcn_readlane(lf, (int)__builtin_ctzll(has));
-                }
-            }
-            // gap test, branch-free: distance from the previous block end (a huge "previous" when there is none)
-            const int none = 0x3fffffff;
-            const int pin = prev_in == 0 ? none : prev_in;
-            const int pv1 = run[0] ? run[0] : pin, pv2 = run[1] ? run[1] : pin, pv3 = run[2] ? run[2] : pin;
-            const bool h0 = aln[0] && (ref[0] - pin > min_gap);
-            const bool h1 = aln[1] && (ref[1] - pv1 > min_gap);
-            const bool h2 = aln[2] && (ref[2] - pv2 > min_gap);
-            const bool h3 = aln[3] && (ref[3] - pv3 > min_gap);
-            if (gaps_on && __ballot(h0 | h1 | h2 | h3) != 0ull) {          // rare: some lane holds a large gap
-                const int pv[4] = {pin, pv1, pv2, pv3};
-                const bool hit[4] = {h0, h1, h2, h3};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (hit[k]) {
-                        const uint32_t slot = atomicAdd(gap_count, 1u);
-                        if (slot < gap_cap) {
-                            int4 row = make_int4((int)pr, (pc + j * WAVE + lane) * 4 + k, p0 + pv[k], p0 + ref[k]);
-                            reinterpret_cast<int4 *>(gaps)[slot] = row;
-                        }
-                    }
-                }
-            }
-            carry_end = max(carry_end, __builtin_amdgcn_readlane(mx, 63));
-            }
-            carry_ref += __builtin_amdgcn_readlane(incl, 63);
         }
-
-        if (pc + BATCH * WAVE >= pnq) {          // last batch of this record: write its summary, move on
-            const int ms = wave_sum_dpp(msum);
-            const int qs = wave_sum_dpp(qsum);
-            if (lane == 0) {
-                mbases[pr] = ms;
-                qinfer[pr] = qs;
-                blk_first[pr] = (carry_end > 0) ? p0 + first : -1;
-                blk_last[pr] = (carry_end > 0) ? p0 + carry_end : -1;
-            }
-            carry_ref = 0; carry_end = 0; msum = 0; qsum = 0; first = 0;
-            tail_flagged = false;
-            pr = next_rec(pr);
-            p_meta();
-        } else {
-            pc += BATCH * WAVE;
-        }
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) cur[j] = nxt[j];
+        st.carry_end = max(st.carry_end, __builtin_amdgcn_readlane(mx, 63));
     }
+    st.carry_ref += __builtin_amdgcn_readlane(incl, 63);
 }
 
-// The alternative kernel structures that were measured and rejected (flat, packed, ring, ring + counted waits, tile stream)
-#include "coral_scan_experiments.hip.inc"
-
-// Streaming-read probe: what a plain grid-stride 16-byte-per-lane read of the same CIGAR bytes achieves
-// (upper bound for any kernel that must touch every op once).
-__global__ __launch_bounds__(256) void k_stream_probe(const cquad_t *__restrict__ q, long long n_quads, uint32_t *__restrict__ out) {
-    const long long stride = (long long)gridDim.x * 256 * 4;
-    uint32_t acc = 0;
-    for (long long i = (long long)blockIdx.x * 256 * 4 + threadIdx.x; i < n_quads; i += stride) {
-        cquad_t a = q[i], b = pad_or(q, i + 256, n_quads), c = pad_or(q, i + 512, n_quads), d = pad_or(q, i + 768, n_quads);
-        acc += a[0] ^ a[1] ^ a[2] ^ a[3] ^ b[0] ^ b[1] ^ b[2] ^ b[3] ^ c[0] ^ c[1] ^ c[2] ^ c[3] ^ d[0] ^ d[1] ^ d[2] ^ d[3];
+// First record r in [0, n_rec] with cigar_off[r] >= target (cigar_off ascending, n_rec + 1 entries): 64 probes per step.
+__device__ __forceinline__ long long first_record_at(const int64_t *__restrict__ cigar_off, long long n_rec, long long target, int lane) {
+    long long lo = 0, hi = n_rec;                 // answer in [lo, hi]
+    while (hi - lo > 64) {
+        const long long idx = lo + ((hi - lo) * (long long)(lane + 1)) / 65;        // lo < idx_0 < ... < idx_63 < hi
+        const bool ge = cigar_off[idx] >= target;
+        const unsigned long long m = __ballot(ge);                                  // 0..0 1..1 from some lane on
+        const int f = m == 0ull ? 64 : (int)__builtin_ctzll(m);                     // first lane whose probe is >= target
+        const long long lo_new = f == 0 ? lo : (lo + ((hi - lo) * (long long)f) / 65) + 1;
+        const long long hi_new = f == 64 ? hi : lo + ((hi - lo) * (long long)(f + 1)) / 65;
+        lo = lo_new;
+        hi = hi_new;
     }
-    if (acc == 0x9e3779b9u) out[0] = acc;      // never true in practice; keeps the loads alive
+    const long long idx = lo + lane;
+    const bool ge = idx <= hi && cigar_off[idx <= n_rec ? idx : n_rec] >= target;
+    const unsigned long long m = __ballot(ge);
+    return m == 0ull ? hi : lo + (long long)__builtin_ctzll(m);
 }
 
-// Probe 2: every wave streams its own contiguous region (n_quads / n_waves quads), 4 KiB per iteration.
-__global__ __launch_bounds__(256) void k_stream_probe_regions(const cquad_t *__restrict__ q, long long n_quads, uint32_t *__restrict__ out) {
+// LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to the wave-uniform LDS byte address `lds_dst` (+ lane * 16).
+// M0 carries the LDS base and is compiler-reserved: save / set / restore inside the one statement (guide: cdna_hip_programming.md §10).
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int RING>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v3(
+    long long n_rec, const int32_t *__restrict__ pos, const int32_t *__restrict__ flagmq,
+    const int64_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar, int min_gap, int min_mapq,
+    int4 *__restrict__ summary, int32_t *__restrict__ gaps, uint32_t *__restrict__ gap_count, uint32_t gap_cap) {
+    __shared__ cquad_t lds[SCAN_BLOCK / WAVE][RING + 1][WAVE];        // per wave: RING slots of 1 KiB + 1 KiB of parked summaries
     const int lane = threadIdx.x & 63;
-    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long nwaves = (long long)gridDim.x * 4;
-    const long long per = (n_quads + nwaves - 1) / nwaves;
-    const long long a = wave * per, b = (a + per < n_quads) ? a + per : n_quads;
-    uint32_t acc = 0;
-    for (long long i = a + lane; i < b; i += 256) {
-        cquad_t x0 = q[i], x1 = pad_or(q, i + 64, b), x2 = pad_or(q, i + 128, b), x3 = pad_or(q, i + 192, b);
-        acc += x0[0] ^ x0[1] ^ x0[2] ^ x0[3] ^ x1[0] ^ x1[1] ^ x1[2] ^ x1[3] ^ x2[0] ^ x2[1] ^ x2[2] ^ x2[3] ^ x3[0] ^ x3[1] ^ x3[2] ^ x3[3];
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long wave = (long long)blockIdx.x * (SCAN_BLOCK / WAVE) + wib;
+    const long long nwaves = (long long)gridDim.x * (SCAN_BLOCK / WAVE);
+    const cquad_t pad = {OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD};
+    const cquad_t *__restrict__ qbase = reinterpret_cast<const cquad_t *>(cigar);
+
+    // ---- this wave's records: those whose first quad lies in the wave-th of nwaves equal slices of the quad stream
+    const long long total_q = cigar_off[n_rec] >> 2;
+    const long long ra = wave == 0 ? 0 : first_record_at(cigar_off, n_rec, 4 * ((total_q * wave) / nwaves), lane);
+    const long long rb = wave == nwaves - 1 ? n_rec : first_record_at(cigar_off, n_rec, 4 * ((total_q * (wave + 1)) / nwaves), lane);
+    if (ra >= rb) return;                                        // (wave-uniform)
+    const long long s0 = cigar_off[ra] >> 2, s1 = cigar_off[rb] >> 2;      // quad range of the wave
+    const long long base = s0 & ~7ll;                            // loads start on a 128-byte line
+    const long long n_chunks = (s1 - base + WAVE - 1) / WAVE;    // may be 0 (only empty records)
+    const uint32_t lds_wave = (uint32_t)(uintptr_t)&lds[wib][0][0];       // LDS byte address of the wave's ring
+
+    auto issue = [&](long long c) {                              // chunk c -> slot c % RING; never reads past the stream's end
+        const long long q = base + c * WAVE + lane;
+        if (q < total_q) glds16(qbase + q, lds_wave + (uint32_t)(c % RING) * (WAVE * 16));
+    };
+    for (long long c = 0; c < RING && c < n_chunks; ++c) issue(c);
+
+    // ---- record cursor (metadata is wave-uniform: scalar loads, requested one record ahead)
+    long long r = ra;
+    long long rec_start = s0, rec_end = cigar_off[ra + 1] >> 2;
+    int p0 = pos[ra];
+    bool gaps_on = ((flagmq[ra] >> 16) & 0xff) >= min_mapq;
+    const long long last_rec = n_rec - 1;
+    long long n_end = 0;
+    int n_pos = 0, n_fm = 0;
+    auto request = [&](long long rr) {                           // unconditional (clamped) loads: no select on the loaded value
+        const long long c = rr < n_rec ? rr : last_rec;
+        n_end = cigar_off[c + 1];
+        n_pos = pos[c];
+        n_fm = flagmq[c];
+    };
+    request(ra + 1);
+    ScanState st = {0, 0, 0, 0, 0, false};
+    const int half_gap = min_gap >> 1;
+    int parked = 0;                                              // summaries waiting in LDS (wave-uniform)
+    int4 *park = reinterpret_cast<int4 *>(&lds[wib][RING][0]);
+    auto flush = [&]() {                                         // `parked` rows -> summary[r - parked .. r)
+        if (lane < parked) summary[r - parked + lane] = park[lane];
+        parked = 0;
+    };
+    auto finish_record = [&]() {
+        const int ms = wave_sum_dpp(st.msum);
+        const int qs = wave_sum_dpp(st.qsum);
+        if (lane == 0) park[parked] = make_int4(ms, qs, st.carry_end > 0 ? p0 + st.first : -1, st.carry_end > 0 ? p0 + st.carry_end : -1);
+        ++parked;
+        st = {0, 0, 0, 0, 0, false};
+        ++r;
+        if (parked == WAVE) flush();
+        rec_start = rec_end;
+        rec_end = n_end >> 2;
+        p0 = n_pos;
+        gaps_on = ((n_fm >> 16) & 0xff) >= min_mapq;
+        request(r + 1);
+    };
+
+    for (long long c = 0; c < n_chunks; ++c) {
+        // retire the oldest slot: with RING loads in flight, at most RING - 1 may remain (the tail of the range simply drains)
+        if (c + RING <= n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING - 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cquad_t quad = lds[wib][c % RING][lane];
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(quad)::"memory");        // the read has landed: its slot may be refilled
+        if (c + RING < n_chunks) issue(c + RING);
+        const long long cq0 = base + c * WAVE, cq1 = cq0 + WAVE;
+        if (rec_start <= cq0 && rec_end > cq1) {                 // (wave-uniform) the chunk lies inside the current record
+            scan_piece(quad, lane, st, gaps_on, min_gap, half_gap, (int)r, (int)(cq0 - rec_start), p0, gaps, gap_count, gap_cap);
+            continue;
+        }
+        const long long lq = cq0 + lane;
+        while (r < rb) {                                         // once per record present in this chunk
+            const long long a = rec_start > cq0 ? rec_start : cq0, b = rec_end < cq1 ? rec_end : cq1;
+            if (b > a) {
+                cquad_t piece = pad;
+                if (lq >= a && lq < b) piece = quad;
+                scan_piece(piece, lane, st, gaps_on, min_gap, half_gap, (int)r, (int)(cq0 - rec_start), p0, gaps, gap_count, gap_cap);
+            }
+            if (rec_end > cq1) break;                            // the record continues in the next chunk
+            finish_record();
+            if (rec_start >= cq1) break;                         // the next record starts in a later chunk
+        }
     }
-    if (acc == 0x9e3779b9u) out[0] = acc;
+    while (r < rb) finish_record();                              // records without any op at the end of the range
+    if (parked) flush();
 }
 
-static int g_probe_mode = 1;
-extern "C" int coral_set_probe_mode(int m) { g_probe_mode = m; return CORAL_OK; }
-
-extern "C" int coral_time_stream_read(const uint32_t *cigar, long long n_words, uint32_t *scratch, int iters, float *ms, void *stream) {
-    if (!cigar || !scratch || !ms || iters < 1) return set_err(CORAL_ERR_ARG, "time_stream_read: bad arguments");
-    hipEvent_t a, b;
-    (void)hipEventCreate(&a);
-    (void)hipEventCreate(&b);
-    hipStream_t s = (hipStream_t)stream;
-    (void)hipEventRecord(a, s);
-    for (int i = 0; i < iters; ++i) {
-        if (g_probe_mode == 1)
-            hipLaunchKernelGGL(k_stream_probe, dim3(2048), dim3(256), 0, s, reinterpret_cast<const cquad_t *>(cigar), n_words / 4, scratch);
-        else
-            hipLaunchKernelGGL(k_stream_probe_regions, dim3(2048), dim3(256), 0, s, reinterpret_cast<const cquad_t *>(cigar), n_words / 4, scratch);
-    }
-    (void)hipEventRecord(b, s);
-    hipError_t e = hipEventSynchronize(b);
-    float t = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&t, a, b);
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
-    if (e != hipSuccess) return hip_err(e, "time_stream_read");
-    *ms = t / (float)iters;
-    return CORAL_OK;
-}
-
-static int g_scan_variant = 15;  // 8 KiB per wave in flight + conservative gap filter + tiles of 8 consecutive records per wave: best launch time (profiles/r01_scan_variants.md)
-extern "C" int coral_set_scan_variant(int v) {
-    if (v < 1 || v > 27) return CORAL_ERR_ARG;
-    g_scan_variant = v;
-    return CORAL_OK;
-}
-
-static int scan_grid(long long n_rec) {
-    long long blocks = (n_rec + (SCAN_BLOCK / WAVE) - 1) / (SCAN_BLOCK / WAVE);
-    const long long cap = 256 * 8;   // 256 CUs x 8 workgroups of 4 waves = 32 waves per CU
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    return (int)blocks;
-}
-
-static int tile_grid(long long n_rec, int tile) {      // one wave per tile up to the resident-wave cap
-    const long long tiles = (n_rec + tile - 1) / tile;
-    long long blocks = (tiles + (SCAN_BLOCK / WAVE) - 1) / (SCAN_BLOCK / WAVE);
-    const long long cap = 256 * 8;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    return (int)blocks;
-}
+extern "C" const char *coral_scan_kernel_name(void) { return "k_cigar_scan_v3<8>"; }
 
 static int check_records(const coral_records_t *rec) {
     if (!rec) return set_err(CORAL_ERR_ARG, "records: null");
@@ -533,140 +348,34 @@ static int check_records(const coral_records_t *rec) {
     return CORAL_OK;
 }
 
-extern "C" int coral_cigar_scan(const coral_records_t *rec, int32_t min_gap, int32_t min_mapq,
-                                int32_t *mbases, int32_t *qinfer, int32_t *blk_first, int32_t *blk_last,
-                                int32_t *gaps, uint32_t *gap_count, uint32_t gap_cap, void *stream) {
+// workgroups of the scan: as many as are resident at once (LDS-bound: 36 KiB per workgroup -> 4 per CU), never more waves than records
+static int scan_grid(long long n_rec) {
+    static int resident = 0;
+    if (resident == 0) {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cigar_scan_v3<8>, SCAN_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            cus = 256;
+        resident = per_cu * cus;
+    }
+    long long blocks = (n_rec + (SCAN_BLOCK / WAVE) - 1) / (SCAN_BLOCK / WAVE);
+    if (blocks > resident) blocks = resident;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+extern "C" int coral_cigar_scan(const coral_records_t *rec, int32_t min_gap, int32_t min_mapq, int32_t *summary, int32_t *gaps,
+                                uint32_t *gap_count, uint32_t gap_cap, void *stream) {
     int rc = check_records(rec);
     if (rc) return rc;
     if (rec->n_rec == 0) return CORAL_OK;
-    if (!mbases || !qinfer || !blk_first || !blk_last || !gap_count || (gap_cap && !gaps))
-        return set_err(CORAL_ERR_ARG, "cigar_scan: null output");
-    if (((uintptr_t)gaps) & 15u) return set_err(CORAL_ERR_ARG, "cigar_scan: gaps must be 16-byte aligned");
-    if (g_scan_variant == 1)
-        hipLaunchKernelGGL(k_cigar_scan, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
-                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
-                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
-#define LAUNCH_V2(B)                                                                                                  \
-    hipLaunchKernelGGL(k_cigar_scan_v2<B>, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,     \
-                       (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,        \
-                       (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap)
-    else if (g_scan_variant == 2)
-        LAUNCH_V2(4);
-    else if (g_scan_variant == 4)
-        LAUNCH_V2(2);
-    else if (g_scan_variant == 6)
-        hipLaunchKernelGGL(k_cigar_scan_flat<4>, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
-                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
-                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
-    else if (g_scan_variant == 8)
-        hipLaunchKernelGGL(k_cigar_scan_packed<8>, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
-                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
-                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
-    else if (g_scan_variant == 9)
-        hipLaunchKernelGGL(k_cigar_scan_packed<4>, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
-                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
-                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
-#define LAUNCH_RING(B, F)                                                                                             \
-    hipLaunchKernelGGL((k_cigar_scan_ring<B, F>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream, \
-                       (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,        \
-                       (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap)
-#define LAUNCH_RING_ASM(B, F)                                                                                         \
-    hipLaunchKernelGGL((k_cigar_scan_ring_asm<B, F>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream, \
-                       (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,        \
-                       (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap)
-    else if (g_scan_variant == 13)
-        LAUNCH_RING_ASM(8, true);
-    else if (g_scan_variant == 14)
-        LAUNCH_RING_ASM(4, true);
-    else if (g_scan_variant == 10)
-        LAUNCH_RING(8, true);
-    else if (g_scan_variant == 11)
-        LAUNCH_RING(4, true);
-    else if (g_scan_variant == 12)
-        LAUNCH_RING(8, false);
-#define LAUNCH_TILED(B, L, T)                                                                                         \
-    hipLaunchKernelGGL((k_cigar_scan_v2<B, L, true, T>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream, \
-                       (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,        \
-                       (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap)
-#define LAUNCH_TILE(B, T)                                                                                             \
-    hipLaunchKernelGGL((k_cigar_scan_tile<B, T, true>), dim3(tile_grid(rec->n_rec, T)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream, \
-                       (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,        \
-                       (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap)
-    else if (g_scan_variant == 20)
-        LAUNCH_TILE(8, 8);
-    else if (g_scan_variant == 21)
-        LAUNCH_TILE(8, 16);
-    else if (g_scan_variant == 22)
-        LAUNCH_TILE(4, 8);
-    else if (g_scan_variant == 23)
-        hipLaunchKernelGGL((k_cigar_scan_v2<8, false, true, 8, true>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
-                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
-                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
-    else if (g_scan_variant == 24)
-        hipLaunchKernelGGL((k_cigar_scan_v2<4, true, true, 8, true>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
-                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
-                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
-    else if (g_scan_variant == 25)
-        LAUNCH_TILED(4, false, 8);
-    else if (g_scan_variant == 26)
-        LAUNCH_TILED(2, false, 8);
-    else if (g_scan_variant == 27)
-        LAUNCH_TILED(16, false, 8);
-    else if (g_scan_variant == 17)
-        LAUNCH_TILED(8, false, 4);
-    else if (g_scan_variant == 18)
-        LAUNCH_TILED(8, false, 16);
-    else if (g_scan_variant == 19)
-        LAUNCH_TILED(4, true, 8);            // diagnostic: loads and cursors only, tiled (outputs invalid)
-    else if (g_scan_variant == 15)
-        hipLaunchKernelGGL((k_cigar_scan_v2<8, false, true, 8>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
-                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
-                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
-    else if (g_scan_variant == 16)
-        hipLaunchKernelGGL((k_cigar_scan_v2<8, false, true, 32>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
-                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
-                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
-    else if (g_scan_variant == 7)
-        hipLaunchKernelGGL((k_cigar_scan_v2<8, false, true>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
-                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
-                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
-    else if (g_scan_variant == 5)
-        hipLaunchKernelGGL((k_cigar_scan_v2<4, true>), dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,
-                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->n_cigar, rec->cigar_off, rec->cigar,
-                           (int)min_gap, (int)min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap);
-    else
-        LAUNCH_V2(8);
+    if (!summary || !gap_count || (gap_cap && !gaps)) return set_err(CORAL_ERR_ARG, "cigar_scan: null output");
+    if ((((uintptr_t)gaps) & 15u) || (((uintptr_t)summary) & 15u)) return set_err(CORAL_ERR_ARG, "cigar_scan: summary and gaps must be 16-byte aligned");
+    hipLaunchKernelGGL(k_cigar_scan_v3<8>, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream, (long long)rec->n_rec,
+                       rec->pos, rec->flagmq, rec->cigar_off, rec->cigar, (int)min_gap, (int)min_mapq, reinterpret_cast<int4 *>(summary),
+                       gaps, gap_count, gap_cap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_err(e, "cigar_scan launch");
-    return CORAL_OK;
-}
-
-extern "C" int coral_time_cigar_scan(const coral_records_t *rec, int32_t min_gap, int32_t min_mapq,
-                                     int32_t *mbases, int32_t *qinfer, int32_t *blk_first, int32_t *blk_last,
-                                     int32_t *gaps, uint32_t *gap_count, uint32_t gap_cap, int32_t iters,
-                                     float *ms_per_launch, void *stream) {
-    if (!ms_per_launch || iters < 1) return set_err(CORAL_ERR_ARG, "time_cigar_scan: bad arguments");
-    hipEvent_t a, b;
-    hipError_t e = hipEventCreate(&a);
-    if (e != hipSuccess) return hip_err(e, "hipEventCreate");
-    e = hipEventCreate(&b);
-    if (e != hipSuccess) return hip_err(e, "hipEventCreate");
-    hipStream_t s = (hipStream_t)stream;
-    int rc = CORAL_OK;
-    (void)hipEventRecord(a, s);
-    for (int i = 0; i < iters && rc == CORAL_OK; ++i) {
-        (void)hipMemsetAsync(gap_count, 0, sizeof(uint32_t), s);
-        rc = coral_cigar_scan(rec, min_gap, min_mapq, mbases, qinfer, blk_first, blk_last, gaps, gap_count, gap_cap, stream);
-    }
-    (void)hipEventRecord(b, s);
-    e = hipEventSynchronize(b);
-    float ms = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
-    if (rc) return rc;
-    if (e != hipSuccess) return hip_err(e, "time_cigar_scan");
-    *ms_per_launch = ms / (float)iters;
     return CORAL_OK;
 }
 
@@ -695,7 +404,7 @@ __device__ __forceinline__ int first_seg_ending_after(const int32_t *__restrict_
 __global__ __launch_bounds__(COV_BLOCK) void k_seg_classify(
     long long n_rec, const int32_t *__restrict__ tid, const int32_t *__restrict__ pos,
     const int32_t *__restrict__ end, const int32_t *__restrict__ flagmq, const int32_t *__restrict__ n_cigar,
-    const int32_t *__restrict__ mbases, const int32_t *__restrict__ qinfer, int n_seg,
+    const int4 *__restrict__ summary, int n_seg,
     const int32_t *__restrict__ seg_tid, const int32_t *__restrict__ seg_start, const int32_t *__restrict__ seg_end,
     unsigned long long *__restrict__ n_reads, unsigned long long *__restrict__ n_bases,
     uint32_t *__restrict__ strad, uint32_t *__restrict__ strad_count) {
@@ -714,15 +423,16 @@ __global__ __launch_bounds__(COV_BLOCK) void k_seg_classify(
             const int t = tid[r], p = pos[r], e = end[r];
             int j = (t >= 0) ? first_seg_ending_after(seg_tid, seg_end, n_seg, t, p) : n_seg;
             if (j < n_seg && seg_tid[j] == t && seg_start[j] < e) {
-                const bool counts = qinfer[r] > 0;
+                const int4 sm = summary[r];               // mbases, qinfer, first block start, last block end
+                const bool counts = sm.y > 0;
                 const bool has_seq = ((flagmq[r] >> 24) & 1) && n_cigar[r] > 0;
                 if (seg_start[j] <= p && e <= seg_end[j]) {
                     if (use_lds) {
                         if (counts) atomicAdd(&bins[2 * j], 1ull);
-                        if (has_seq) atomicAdd(&bins[2 * j + 1], (unsigned long long)mbases[r]);
+                        if (has_seq) atomicAdd(&bins[2 * j + 1], (unsigned long long)sm.x);
                     } else {
                         if (counts) atomicAdd(&n_reads[j], 1ull);
-                        if (has_seq) atomicAdd(&n_bases[j], (unsigned long long)mbases[r]);
+                        if (has_seq) atomicAdd(&n_bases[j], (unsigned long long)sm.x);
                     }
                 } else {
                     for (; j < n_seg && seg_tid[j] == t && seg_start[j] < e; ++j) {
@@ -809,8 +519,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_seg_walk(
     }
 }
 
-extern "C" int coral_segment_coverage(const coral_records_t *rec, const int32_t *mbases, const int32_t *qinfer,
-                                      int32_t n_seg, const int32_t *seg_tid, const int32_t *seg_start,
+extern "C" int coral_segment_coverage(const coral_records_t *rec, const int32_t *summary, int32_t n_seg, const int32_t *seg_tid, const int32_t *seg_start,
                                       const int32_t *seg_end, unsigned long long *n_reads,
                                       unsigned long long *n_bases, uint32_t *strad, uint32_t *strad_count,
                                       void *stream) {
@@ -818,13 +527,13 @@ extern "C" int coral_segment_coverage(const coral_records_t *rec, const int32_t 
     if (rc) return rc;
     if (n_seg < 0) return set_err(CORAL_ERR_ARG, "segment_coverage: n_seg < 0");
     if (n_seg == 0 || rec->n_rec == 0) return CORAL_OK;
-    if (!mbases || !qinfer || !seg_tid || !seg_start || !seg_end || !n_reads || !n_bases || !strad || !strad_count)
+    if (!summary || !seg_tid || !seg_start || !seg_end || !n_reads || !n_bases || !strad || !strad_count)
         return set_err(CORAL_ERR_ARG, "segment_coverage: null argument");
     hipStream_t s = (hipStream_t)stream;
     long long blocks = (rec->n_rec + COV_BLOCK - 1) / COV_BLOCK;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_seg_classify, dim3((int)blocks), dim3(COV_BLOCK), 0, s, (long long)rec->n_rec, rec->tid,
-                       rec->pos, rec->end, rec->flagmq, rec->n_cigar, mbases, qinfer, (int)n_seg, seg_tid, seg_start,
+                       rec->pos, rec->end, rec->flagmq, rec->n_cigar, reinterpret_cast<const int4 *>(summary), (int)n_seg, seg_tid, seg_start,
                        seg_end, n_reads, n_bases, strad, strad_count);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_err(e, "seg_classify launch");

@@ -20,15 +20,18 @@ PROFILE = {}      # bench.py: PROFILE["scan_ms"] = [] collects (start, end) HIP 
 
 
 class ScanResult:
-    """Per-record CIGAR summaries of the local shard (device tensors) and the large-gap rows of ALL shards.
+    """Per-record CIGAR summaries of the local shard (device tensor ``summary`` int32 [n, 4] = aligned bases, inferred read
+    length, first block start, last block end; the four columns are also available by name) and the large-gap rows of ALL
+    shards.
 
     gaps: int64 [K, 6] = record ordinal (global), op index of the next block, previous block end, next block start,
     first block start, last block end of that record; sorted by (record, op index) — the reference's order.  On one GPU the
     rows are fetched from the device the first time they are asked for, so the launch itself never waits for the kernel.
     """
 
-    def __init__(self, mbases, qinfer, blk_first, blk_last, gaps=None, pending=None):
-        self.mbases, self.qinfer, self.blk_first, self.blk_last = mbases, qinfer, blk_first, blk_last
+    def __init__(self, summary, gaps=None, pending=None):
+        self.summary = summary
+        self.mbases, self.qinfer, self.blk_first, self.blk_last = (summary[:, k] for k in range(4))
         self._gaps, self._pending = gaps, pending
 
     @property
@@ -40,15 +43,12 @@ class ScanResult:
 
 
 def _scan_local(dr, min_gap: int, min_mapq: int, gap_cap: int):
-    """Launch coral_cigar_scan on the local shard; returns the four per-record tensors and a callable that yields the gap rows
-    (int64 [K, 6] device tensor, LOCAL record ordinals) — calling it is the first point that waits for the kernel."""
+    """Launch coral_cigar_scan on the local shard; returns the summary tensor (int32 [n, 4]) and a callable that yields the gap
+    rows (int64 [K, 6] device tensor, LOCAL record ordinals) — calling it is the first point that waits for the kernel."""
     L = _lib.lib()
     dev = dr.device
     n = dr.n
-    mb = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-    qi = torch.empty_like(mb)
-    b0 = torch.empty_like(mb)
-    b1 = torch.empty_like(mb)
+    summary = torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev)
     rs = dr.c_struct()
 
     def launch(cap):
@@ -58,9 +58,8 @@ def _scan_local(dr, min_gap: int, min_mapq: int, gap_cap: int):
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(dev))
-        _lib.check(L.coral_cigar_scan(C.byref(rs), min_gap, min_mapq, mb.data_ptr(), qi.data_ptr(), b0.data_ptr(),
-                                      b1.data_ptr(), gaps.data_ptr(), cnt.data_ptr(), cap, dr.stream()),
-                   "coral_cigar_scan")
+        _lib.check(L.coral_cigar_scan(C.byref(rs), min_gap, min_mapq, summary.data_ptr(), gaps.data_ptr(), cnt.data_ptr(), cap,
+                                      dr.stream()), "coral_cigar_scan")
         if prof is not None:
             e1.record(torch.cuda.current_stream(dev))
             prof.append((e0, e1))
@@ -77,17 +76,16 @@ def _scan_local(dr, min_gap: int, min_mapq: int, gap_cap: int):
             cap = 1 << int(np.ceil(np.log2(k + 1)))          # more gap rows than slots: run again with room for all of them
             state[0], state[1] = launch(cap), cap
         g = gaps[:k].to(torch.int64)
-        return torch.cat([g, b0[:n][g[:, 0]].to(torch.int64)[:, None], b1[:n][g[:, 0]].to(torch.int64)[:, None]], dim=1) \
-            if k else torch.zeros((0, 6), dtype=torch.int64, device=dev)
+        return torch.cat([g, summary[:n][g[:, 0]][:, 2:4].to(torch.int64)], dim=1) if k else torch.zeros((0, 6), dtype=torch.int64, device=dev)
 
-    return mb[:n], qi[:n], b0[:n], b1[:n], rows
+    return summary[:n], rows
 
 
 def cigar_scan(dr, min_gap: int = 600, min_mapq: int = 20, gap_cap: int = 1 << 16, _worker=False) -> ScanResult:
     from . import sharding
     if dr.world > 1 and not _worker:
-        sharding.command(dr, ("scan", min_gap, min_mapq, gap_cap))
-    mb, qi, b0, b1, pending = _scan_local(dr, min_gap, min_mapq, gap_cap)
+        sharding.command(dr, sharding.CMD_SCAN, (min_gap, min_mapq, gap_cap))
+    summary, pending = _scan_local(dr, min_gap, min_mapq, gap_cap)
 
     def gather():
         rows = pending()
@@ -100,8 +98,8 @@ def cigar_scan(dr, min_gap: int = 600, min_mapq: int = 20, gap_cap: int = 1 << 1
         return g
 
     if dr.world > 1:
-        return ScanResult(mb, qi, b0, b1, gaps=gather())      # the exchange is a collective: every rank takes part now
-    return ScanResult(mb, qi, b0, b1, pending=gather)
+        return ScanResult(summary, gaps=gather())      # the exchange is a collective: every rank takes part now
+    return ScanResult(summary, pending=gather)
 
 
 def _disjoint_batches(segs: np.ndarray) -> List[np.ndarray]:
@@ -139,7 +137,7 @@ def _coverage_local(dr, scan: ScanResult, sg: np.ndarray) -> torch.Tensor:
         e = torch.tensor(b[:, 2], dtype=torch.int32, device=dev)
         out = torch.zeros((2, len(batch)), dtype=torch.int64, device=dev)
         cnt = torch.zeros(1, dtype=torch.int32, device=dev)
-        _lib.check(L.coral_segment_coverage(C.byref(rs), scan.mbases.data_ptr(), scan.qinfer.data_ptr(), len(batch),
+        _lib.check(L.coral_segment_coverage(C.byref(rs), scan.summary.data_ptr(), len(batch),
                                             t.data_ptr(), s.data_ptr(), e.data_ptr(), out[0].data_ptr(),
                                             out[1].data_ptr(), strad.data_ptr(), cnt.data_ptr(), dr.stream()),
                    "coral_segment_coverage")
@@ -158,7 +156,7 @@ def segment_coverage(dr, scan: ScanResult, segs: Sequence[Tuple[int, int, int]],
         return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
     sg = np.asarray(segs, dtype=np.int64).reshape(S, 3)
     if dr.world > 1 and not _worker:
-        sharding.command(dr, ("coverage", sg))
+        sharding.command(dr, sharding.CMD_COVERAGE, payload=sg)
     out = _coverage_local(dr, scan, sg)
     if dr.world > 1:
         out = sharding.allreduce_sum(dr, out)
@@ -200,7 +198,7 @@ def point_cover(dr, points: Sequence[Tuple[int, int]], pair_cap: int = 1 << 20, 
         return []
     pts = np.asarray(points, dtype=np.int64).reshape(P, 2)
     if dr.world > 1 and not _worker:
-        sharding.command(dr, ("points", pts, pair_cap))
+        sharding.command(dr, sharding.CMD_POINTS, (pair_cap,), payload=pts)
     uniq, inverse = np.unique(pts, axis=0, return_inverse=True)     # sorted by (tid, pos)
     pairs = _points_local(dr, uniq, pair_cap) + dr.lo                # record ordinal -> global
     if dr.world > 1:

@@ -12,37 +12,113 @@ import torch
 from . import _lib
 
 
+class HostMirrors:
+    """Per-record fields of the WHOLE file the host logic works on (32 bytes per record, no CIGARs) + tokenised SA rows,
+    non-ACGT positions and read names.  Built from one Records object (single process) or from the gathered per-rank
+    pieces (``from_pieces``: every rank decoded its own byte range of the BAM; read-name ids are unified here)."""
+
+    FIELDS = ("tid", "pos", "end", "flag", "mapq", "qlen", "has_seq", "nm", "name_id", "n_cigar", "sa_count", "sa", "sa_nm",
+              "nonacgt_rec", "nonacgt_pos")
+
+    def __init__(self, rec=None):
+        if rec is not None:
+            self._from_arrays(HostMirrors.piece_of(rec), names=rec.names, lazy_names=rec)
+
+    @staticmethod
+    def piece_of(rec) -> dict:
+        """The host-side fields of one Records object as numpy arrays (what a rank contributes to the gather)."""
+        h = lambda t: t.detach().cpu().numpy()
+        sa_off = h(rec.sa_off).astype(np.int64)
+        return dict(tid=h(rec.tid).astype(np.int32), pos=h(rec.pos).astype(np.int32), end=h(rec.end).astype(np.int32),
+                    flag=h(rec.flag).astype(np.int32), mapq=h(rec.mapq).astype(np.int32), qlen=h(rec.qlen).astype(np.int32),
+                    has_seq=h(rec.has_seq).astype(bool), nm=h(rec.nm).astype(np.int32), name_id=h(rec.name_id).astype(np.int32),
+                    n_cigar=h(rec.n_cigar).astype(np.int32), sa_count=np.diff(sa_off).astype(np.int64),
+                    sa=h(rec.sa).astype(np.int32).reshape(-1, 8), sa_nm=h(rec.sa_nm).astype(np.int32),
+                    nonacgt_rec=h(rec.nonacgt_rec).astype(np.int64), nonacgt_pos=h(rec.nonacgt_pos).astype(np.int32),
+                    n_names=int(rec.n_names))
+
+    @classmethod
+    def from_pieces(cls, pieces: List[dict], names_per_piece: List[List[str]]) -> "HostMirrors":
+        """Pieces of consecutive record ranges (rank order = file order), each with range-local name ids: one mirror of
+        the whole file.  Global name ids are given in order of first appearance over the file, exactly what a
+        single-process decode gives."""
+        gid = {}
+        names: List[str] = []
+        remapped = []
+        for piece, local_names in zip(pieces, names_per_piece):
+            lut = np.empty(max(len(local_names), 1), dtype=np.int32)
+            for k, nm in enumerate(local_names):
+                g = gid.get(nm)
+                if g is None:
+                    g = gid[nm] = len(names)
+                    names.append(nm)
+                lut[k] = g
+            remapped.append(lut[piece["name_id"]] if len(piece["name_id"]) else piece["name_id"])
+        cat = lambda k: np.concatenate([p[k] for p in pieces])
+        base = np.cumsum([0] + [len(p["tid"]) for p in pieces])
+        d = {k: cat(k) for k in cls.FIELDS if k not in ("name_id", "nonacgt_rec")}
+        d["name_id"] = np.concatenate(remapped).astype(np.int32)
+        d["nonacgt_rec"] = np.concatenate([p["nonacgt_rec"] + base[i] for i, p in enumerate(pieces)])
+        d["n_names"] = len(names)
+        self = cls()
+        self._from_arrays(d, names=names, lazy_names=None)
+        return self
+
+    def _from_arrays(self, d: dict, names, lazy_names):
+        self.h_tid, self.h_pos, self.h_end = d["tid"], d["pos"], d["end"]
+        self.h_flag, self.h_mapq = d["flag"], d["mapq"]
+        self.h_has_seq = d["has_seq"]
+        self.h_qlen = np.where(self.h_has_seq, d["qlen"], 0).astype(np.int32)      # pysam query_length
+        self.h_nm, self.h_name_id, self.h_n_cigar = d["nm"], d["name_id"], d["n_cigar"]
+        self.h_sa_off = np.concatenate([[0], np.cumsum(d["sa_count"])]).astype(np.int64)
+        self.h_sa, self.h_sa_nm = d["sa"], d["sa_nm"]
+        self.h_nonacgt_rec, self.h_nonacgt_pos = d["nonacgt_rec"], d["nonacgt_pos"]
+        self.n_names = int(d["n_names"])
+        self.n_total = len(self.h_tid)
+        self._names = names
+        self._lazy_names = lazy_names
+
+
 class DeviceRecords:
     """Records of one BAM (or one shard of it) in file order.
 
     Device tensors (HBM):  tid, pos, end, flagmq (flag | mapq<<16 | has_seq<<24), n_cigar : int32[n];
                            cigar_off : int64[n+1] (multiples of 4); cigar : int32[total] (BAM-packed, op-15 padded)
-    Host mirrors (numpy):  the same per-record fields + qlen, nm, name_id, and the tokenised SA rows.
+    Host mirrors (numpy):  the same per-record fields + qlen, nm, name_id, and the tokenised SA rows — of the WHOLE file on the
+                           rank that runs the host logic (rank 0), absent on the other ranks.
     """
 
-    def __init__(self, rec, device="cuda:0", rank=0, world=1, group=None):
-        """``rank``/``world``: this process keeps records [lo, hi) of the file in HBM (a contiguous range balanced
-        by CIGAR-op count); the small host mirrors always describe the whole file."""
+    def __init__(self, rec, device="cuda:0", rank=0, world=1, group=None, *, local_only=False, lo=None, n_total=None, host=None):
+        """``rec``: the records this object takes its device arrays from.
+        Default (``local_only`` False): ``rec`` is the whole file; with ``world`` > 1 this process keeps records [lo, hi) of it
+        in HBM (a contiguous range balanced by CIGAR-op count) and, on rank 0 only, the host mirrors of everything.
+        ``local_only`` True: ``rec`` IS this rank's shard (it decoded only its byte range of the BAM); ``lo`` / ``n_total`` place it
+        in the file and ``host`` (rank 0: HostMirrors of the whole file; other ranks: None) comes from the gather."""
         self.device = torch.device(device)
         dev = self.device
         if dev.type == "cuda":
             torch.cuda.set_device(dev)          # libcoral_hip launches on this device's streams: it must be the thread's current GPU
         self.rank, self.world, self.group = int(rank), int(world), group
-        self.n_total = int(rec.n)
         self.header_chroms = list(rec.header_chroms)
         self.header_lens = list(rec.header_lens)
         off_all = rec.cigar_off
-        if world > 1 and self.n_total > 0:
-            total = int(off_all[-1])
-            cuts = torch.searchsorted(off_all[:-1].contiguous(), torch.tensor([total * r // world for r in range(world + 1)],
-                                                                               dtype=off_all.dtype, device=off_all.device))
-            cuts[0], cuts[-1] = 0, self.n_total
-            self.lo, self.hi = int(cuts[rank]), int(cuts[rank + 1])
+        if local_only:
+            self.n_total = int(n_total)
+            self.lo, self.hi = int(lo), int(lo) + int(rec.n)
+            a, b = 0, int(rec.n)
         else:
-            self.lo, self.hi = 0, self.n_total
-        lo, hi = self.lo, self.hi
-        self.n = hi - lo
-        i32 = lambda t: t[lo:hi].to(device=dev, dtype=torch.int32).contiguous()
+            self.n_total = int(rec.n)
+            if world > 1 and self.n_total > 0:
+                total = int(off_all[-1])
+                cuts = torch.searchsorted(off_all[:-1].contiguous(), torch.tensor([total * r // world for r in range(world + 1)],
+                                                                                   dtype=off_all.dtype, device=off_all.device))
+                cuts[0], cuts[-1] = 0, self.n_total
+                self.lo, self.hi = int(cuts[rank]), int(cuts[rank + 1])
+            else:
+                self.lo, self.hi = 0, self.n_total
+            a, b = self.lo, self.hi
+        self.n = b - a
+        i32 = lambda t: t[a:b].to(device=dev, dtype=torch.int32).contiguous()
         self.tid = i32(rec.tid)
         self.pos = i32(rec.pos)
         self.end = i32(rec.end)
@@ -50,9 +126,11 @@ class DeviceRecords:
                  ((rec.has_seq.to(torch.int64) & 1) << 24)
         self.flagmq = i32(flagmq)
         self.n_cigar = i32(rec.n_cigar)
-        c0 = int(off_all[lo]) if self.n_total else 0
-        c1 = int(off_all[hi]) if self.n_total else 0
-        self.cigar_off = (off_all[lo:hi + 1] - c0).to(device=dev, dtype=torch.int64).contiguous()
+        have = int(rec.n) > 0
+        c0 = int(off_all[a]) if have else 0
+        c1 = int(off_all[b]) if have else 0
+        self.cigar_off = (off_all[a:b + 1] - c0).to(device=dev, dtype=torch.int64).contiguous() if have else \
+            torch.zeros(1, dtype=torch.int64, device=dev)
         self.cigar = rec.cigar[c0:c1].to(device=dev, dtype=torch.int32).contiguous()
         if self.cigar.numel() == 0:
             self.cigar = torch.zeros(4, dtype=torch.int32, device=dev)
@@ -64,46 +142,49 @@ class DeviceRecords:
             assert int(self.cigar_off[-1]) <= self.cigar.numel(), "cigar array shorter than its offsets"
             span = self.cigar_off[1:] - self.cigar_off[:-1]
             assert bool((span >= ((self.n_cigar.to(torch.int64) + 3) // 4) * 4).all()), "record ops exceed their slot"
-        # host mirrors
-        h = lambda t: t.detach().cpu().numpy()
-        self.h_tid = h(rec.tid).astype(np.int32)
-        self.h_pos = h(rec.pos).astype(np.int32)
-        self.h_end = h(rec.end).astype(np.int32)
-        self.h_flag = h(rec.flag).astype(np.int32)
-        self.h_mapq = h(rec.mapq).astype(np.int32)
-        self.h_has_seq = h(rec.has_seq).astype(bool)
-        self.h_qlen = np.where(self.h_has_seq, h(rec.qlen), 0).astype(np.int32)    # pysam query_length
-        self.h_nm = h(rec.nm).astype(np.int32)
-        self.h_name_id = h(rec.name_id).astype(np.int32)
-        self.h_n_cigar = h(rec.n_cigar).astype(np.int32)
-        self.h_sa_off = h(rec.sa_off).astype(np.int64)
-        self.h_sa = h(rec.sa).astype(np.int32)
-        self.h_sa_nm = h(rec.sa_nm).astype(np.int32)
-        self.h_nonacgt_rec = h(rec.nonacgt_rec).astype(np.int64)
-        self.h_nonacgt_pos = h(rec.nonacgt_pos).astype(np.int32)
-        self.n_names = int(rec.n_names)
+        self.total_ops = int(rec.n_cigar[a:b].to(torch.int64).sum()) if have else 0
+        self.n_sa_local = int(rec.sa_off[b] - rec.sa_off[a]) if have else 0
         from .global_names import chr_idx
         self.chr_rank = np.array([chr_idx.get(c, -1) for c in self.header_chroms], dtype=np.int32)     # gn:13-18; -1 = other contig
-        self._rec = rec
-        self._names: Optional[List[str]] = rec.names
-        self.total_ops_all = int(self.h_n_cigar.astype(np.int64).sum())
-        self.total_ops = int(self.h_n_cigar[lo:hi].astype(np.int64).sum())
-        self.n_sa_local = int(self.h_sa_off[hi] - self.h_sa_off[lo]) if self.n_total else 0
-        self.n_sa = int(self.h_sa.shape[0])
-        # per-contig record ranges of the coordinate-sorted file; unplaced reads (refID -1) sit at the END of a sorted BAM, so
-        # the binary search runs over the mapped prefix only
-        n_mapped = int(np.count_nonzero(self.h_tid >= 0))
-        mapped = self.h_tid[:n_mapped]
-        if n_mapped and (bool((mapped < 0).any()) or bool((np.diff(mapped) < 0).any())):
-            raise ValueError("records are not sorted by contig (mapped records first, in header order): sort the BAM by coordinate")
-        t = np.arange(len(self.header_chroms))
-        self.tid_lo = np.searchsorted(mapped, t, side="left")
-        self.tid_hi = np.searchsorted(mapped, t, side="right")
+        # ---- host mirrors of the whole file: only where the host logic runs
+        if local_only:
+            mirrors = host
+        else:
+            mirrors = HostMirrors(rec) if (self.rank == 0) else None
+        self.has_host = mirrors is not None
+        self._rec = rec                           # (tests: the CPU stand-ins of the kernels read the records from here)
+        self._rec_offset = self.lo if local_only else 0      # ordinal in the file of self._rec's first record
+        if mirrors is not None:
+            for k, v in vars(mirrors).items():
+                if k.startswith("h_"):
+                    setattr(self, k, v)
+            self.n_names = mirrors.n_names
+            self._names: Optional[List[str]] = mirrors._names
+            self._lazy_names = mirrors._lazy_names
+            assert mirrors.n_total == self.n_total, "host mirrors do not describe the whole file"
+            self.total_ops_all = int(self.h_n_cigar.astype(np.int64).sum())
+            self.n_sa = int(self.h_sa.shape[0])
+            # per-contig record ranges of the coordinate-sorted file; unplaced reads (refID -1) sit at the END of a sorted BAM,
+            # so the binary search runs over the mapped prefix only
+            n_mapped = int(np.count_nonzero(self.h_tid >= 0))
+            mapped = self.h_tid[:n_mapped]
+            if n_mapped and (bool((mapped < 0).any()) or bool((np.diff(mapped) < 0).any())):
+                raise ValueError("records are not sorted by contig (mapped records first, in header order): sort the BAM by coordinate")
+            t = np.arange(len(self.header_chroms))
+            self.tid_lo = np.searchsorted(mapped, t, side="left")
+            self.tid_hi = np.searchsorted(mapped, t, side="right")
+        else:
+            # a rank that only serves kernels: no per-record host data at all
+            self.h_nonacgt_rec = np.zeros(0, dtype=np.int64)
+            self.h_nonacgt_pos = np.zeros(0, dtype=np.int32)
+            self.h_tid = np.zeros(0, dtype=np.int32)
+            self.n_names, self._names, self._lazy_names = 0, [], None
+            self.total_ops_all, self.n_sa = self.total_ops, 0
 
     @property
     def names(self) -> List[str]:
         if self._names is None:
-            self._names = self._rec.materialise_names()
+            self._names = self._lazy_names.materialise_names()
         return self._names
 
     def algorithmic_bytes(self) -> int:
@@ -117,6 +198,7 @@ class DeviceRecords:
 
     def sa_device_arrays(self):
         """Device copies of what coral_sa_table reads (whole file; uploaded once, ~40 B per SA row + 16 B per record)."""
+        assert self.has_host, "the SA table is built where the host logic runs (rank 0)"
         if getattr(self, "_sa_dev", None) is None:
             up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
             flagmq = (self.h_flag.astype(np.int64) & 0xFFFF) | ((self.h_mapq.astype(np.int64) & 0xFF) << 16)

@@ -1,18 +1,26 @@
 """Multi-GPU sharding of the graph build: one process per GPU, torch.distributed over RCCL.
 
-Records are split into ``world`` contiguous (tid, pos)-ordered ranges balanced by CIGAR-op count; every per-record
-kernel runs on the local range only.  The path has two real exchange steps and only those use a collective:
+Input side: every rank decodes ITS byte range of the BAM (coral_bam_decode_range) and uploads only that shard; the per-record
+host fields the order-sensitive host logic needs (32 bytes per record, no CIGARs) and the read names are gathered ONCE to
+rank 0, which unifies the range-local read-name ids (``load_bam_sharded``).  Synthetic benchmarks instead slice records that
+already sit on the GPU (``shard_records``).
+
+Per build: every per-record kernel runs on the local shard only.  The path has two real exchange steps and only those use a
+collective:
   * all-gather-v of the compacted candidate rows (large-gap rows, point-cover pairs), tagged with GLOBAL record
     ordinals and re-sorted into the single-GPU (= reference) iteration order;
   * all-reduce(sum, int64) of the per-segment (n_reads, n_bases) vectors — integer sums, identical for any world.
-Rank 0 runs the small order-sensitive host logic and tells the other ranks which kernel to run next by broadcasting
-a tiny command object; ranks > 0 sit in ``serve``.  Works with backend "nccl" (RCCL over xGMI) and, for the CPU
-tests, "gloo".
+Rank 0 runs the small order-sensitive host logic and tells the other ranks which kernel to run next with a fixed-size int64
+command tensor (+ one int64 payload tensor whose shape the command carries); ranks > 0 sit in ``serve``.  Works with backend
+"nccl" (RCCL over xGMI) and, for the CPU tests, "gloo".
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 import torch.distributed as dist
+
+CMD_DONE, CMD_SCAN, CMD_COVERAGE, CMD_POINTS = 0, 1, 2, 3
 
 
 def shard_records(rec, rank: int, world: int, device, group=None):
@@ -20,10 +28,34 @@ def shard_records(rec, rank: int, world: int, device, group=None):
     return DeviceRecords(rec, device, rank=rank, world=world, group=group)
 
 
-def command(dr, cmd):
-    """Rank 0 -> all: the next kernel to run (called from the public wrappers in coral_amd.kernels)."""
+def _comm_device(dr):
+    """Where collective buffers live: the GPU with RCCL, host memory with gloo."""
+    return torch.device("cpu") if dist.get_backend(dr.group) == "gloo" else dr.device
+
+
+def command(dr, op: int, params=(), payload=None):
+    """Rank 0 -> all: the next kernel to run (called from the public wrappers in coral_amd.kernels).  One int64[8] header
+    (op, three parameters, payload rows, payload columns) and, if the command has one, one int64 payload tensor."""
     assert dr.rank == 0
-    dist.broadcast_object_list([cmd], src=0, group=dr.group)
+    dev = _comm_device(dr)
+    rows, cols = (payload.shape if payload is not None else (0, 0))
+    head = torch.tensor([op] + [int(p) for p in params] + [0] * (3 - len(params)) + [rows, cols, 0, 0], dtype=torch.int64, device=dev)
+    dist.broadcast(head, src=0, group=dr.group)
+    if rows:
+        dist.broadcast(torch.as_tensor(np.ascontiguousarray(payload, dtype=np.int64)).to(dev), src=0, group=dr.group)
+
+
+def _receive(dr):
+    dev = _comm_device(dr)
+    head = torch.zeros(8, dtype=torch.int64, device=dev)
+    dist.broadcast(head, src=0, group=dr.group)
+    h = head.tolist()
+    payload = None
+    if h[4]:
+        buf = torch.zeros((h[4], h[5]), dtype=torch.int64, device=dev)
+        dist.broadcast(buf, src=0, group=dr.group)
+        payload = buf.cpu().numpy()
+    return h[0], h[1:4], payload
 
 
 def _via_host(dr, t: torch.Tensor) -> bool:
@@ -32,7 +64,8 @@ def _via_host(dr, t: torch.Tensor) -> bool:
 
 
 def allgather_rows(dr, rows: torch.Tensor) -> torch.Tensor:
-    """All-gather-v of an int64 [k, c] row tensor (k differs per rank), concatenated in rank order."""
+    """All-gather-v of an int64 [k, c] row tensor (k differs per rank), concatenated in rank order: the row counts are
+    exchanged first, then every rank contributes its rows padded to the largest count (the rows are a few KB)."""
     if _via_host(dr, rows):
         return allgather_rows(dr, rows.cpu()).to(rows.device)
     dev = rows.device
@@ -65,19 +98,17 @@ def serve(dr):
     from . import kernels
     scan = None
     while True:
-        box = [None]
-        dist.broadcast_object_list(box, src=0, group=dr.group)
-        cmd = box[0]
-        if cmd[0] == "done":
+        op, params, payload = _receive(dr)
+        if op == CMD_DONE:
             return
-        if cmd[0] == "scan":
-            scan = kernels.cigar_scan(dr, cmd[1], cmd[2], cmd[3], _worker=True)
-        elif cmd[0] == "coverage":
-            kernels.segment_coverage(dr, scan, cmd[1], _worker=True)
-        elif cmd[0] == "points":
-            kernels.point_cover(dr, cmd[1], cmd[2], _worker=True)
+        if op == CMD_SCAN:
+            scan = kernels.cigar_scan(dr, params[0], params[1], params[2], _worker=True)
+        elif op == CMD_COVERAGE:
+            kernels.segment_coverage(dr, scan, payload, _worker=True)
+        elif op == CMD_POINTS:
+            kernels.point_cover(dr, payload, params[0], _worker=True)
         else:
-            raise RuntimeError("unknown command %r" % (cmd,))
+            raise RuntimeError("unknown command %r" % (op,))
 
 
 def build_graph_sharded(dr, seedfile, cn_seg, output_prefix=None, min_bp_support=1.0, output_bp=False, gc_policy="pause"):
@@ -89,7 +120,77 @@ def build_graph_sharded(dr, seedfile, cn_seg, output_prefix=None, min_bp_support
         try:
             b = ibg.build_graph_from_records(dr, seedfile, cn_seg, output_prefix, min_bp_support, output_bp, gc_policy=gc_policy)
         finally:
-            dist.broadcast_object_list([("done",)], src=0, group=dr.group)
+            command(dr, CMD_DONE)
         return b
     serve(dr)
     return None
+
+
+# ----------------------------------------------------------------------------------------------
+# input side: every rank decodes and uploads its own byte range of the BAM
+# ----------------------------------------------------------------------------------------------
+def _gather_bytes(dr, blob: bytes):
+    """Variable-length byte strings of all ranks on rank 0 (None elsewhere): sizes first, then one padded gather."""
+    dev = _comm_device(dr)
+    n = torch.tensor([len(blob)], dtype=torch.int64, device=dev)
+    ns = [torch.zeros_like(n) for _ in range(dr.world)]
+    dist.all_gather(ns, n, group=dr.group)
+    ns = [int(x.item()) for x in ns]
+    nmax = max(max(ns), 1)
+    buf = torch.zeros(nmax, dtype=torch.uint8, device=dev)
+    if len(blob):
+        buf[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    outs = [torch.empty_like(buf) for _ in range(dr.world)] if dr.rank == 0 else None
+    if dist.get_backend(dr.group) == "gloo":
+        dist.gather(buf, outs, dst=0, group=dr.group)
+    else:                                     # RCCL: gather = all ranks send, rank 0 receives
+        all_outs = [torch.empty_like(buf) for _ in range(dr.world)]
+        dist.all_gather(all_outs, buf, group=dr.group)
+        outs = all_outs if dr.rank == 0 else None
+    if dr.rank != 0:
+        return None
+    return [o[:k].cpu().numpy().tobytes() for o, k in zip(outs, ns)]
+
+
+def load_bam_sharded(path: str, rank: int, world: int, device, group=None, n_threads=None):
+    """Per-rank input: decode the rank's byte range of the BAM, upload only that shard, and gather — once — the per-record
+    host fields and the read names to rank 0 (which unifies the range-local name ids).  Returns DeviceRecords; its host
+    mirrors describe the whole file on rank 0 and are absent elsewhere."""
+    import io
+    from . import bam
+    from .records import DeviceRecords, HostMirrors
+    rec = bam.decode_bam(path, n_threads=n_threads, rank=rank, world=world)
+    stats = dict(bam.LAST_DECODE)
+    if world == 1:
+        dr = DeviceRecords(rec, device)
+        dr.decode_stats = stats
+        return dr
+
+    class _G:                                  # what the gather helpers need before the DeviceRecords exists
+        pass
+    g = _G()
+    g.rank, g.world, g.group, g.device = rank, world, group, torch.device(device)
+    piece = HostMirrors.piece_of(rec)
+    bio = io.BytesIO()
+    np.savez(bio, **{k: v for k, v in piece.items() if k != "n_names"})
+    pieces_raw = _gather_bytes(g, bio.getvalue())
+    names_raw = _gather_bytes(g, "\n".join(rec.names).encode())
+    counts = torch.tensor([rec.n], dtype=torch.int64, device=_comm_device(g))
+    all_counts = [torch.zeros_like(counts) for _ in range(world)]
+    dist.all_gather(all_counts, counts, group=group)
+    all_counts = [int(c.item()) for c in all_counts]
+    lo = sum(all_counts[:rank])
+    host = None
+    if rank == 0:
+        pieces, names = [], []
+        for raw, nraw in zip(pieces_raw, names_raw):
+            z = np.load(io.BytesIO(raw))
+            d = {k: z[k] for k in z.files}
+            local_names = nraw.decode().split("\n") if nraw else []
+            d["n_names"] = len(local_names)
+            pieces.append(d)
+            names.append(local_names)
+        host = HostMirrors.from_pieces(pieces, names)
+    dr = DeviceRecords(rec, device, rank=rank, world=world, group=group, local_only=True, lo=lo, n_total=sum(all_counts), host=host)
+    dr.decode_stats = stats
+    return dr

@@ -60,21 +60,21 @@ const char *coral_last_error(void);
  *
  * Replaces the per-record `get_blocks()` walk and block loop of find_smalldel_breakpoints
  * (/root/reference/src/infer_breakpoint_graph.py:750-762), and pre-computes what the later
- * coverage calls need per record so the CIGAR bytes are streamed once:
- *   mbases[i]    Σ length of M/=/X ops        (what count_coverage adds for a fully covered record,
- *                                               infer_breakpoint_graph.py:131, :1033)
- *   qinfer[i]    Σ length of M/I/S/H/=/X ops  (pysam infer_read_length(), :1031)
- *   blk_first[i] start of the first aligned block, blk_last[i] end of the last one (-1: none)
- *                                              (blocks[0][0], blocks[-1][1] at :760)
- * and appends one row (record, op index of the next block, prev block end, next block start) to
+ * coverage calls need per record so the CIGAR bytes are streamed once.  summary[i] is one 16-byte row:
+ *   [0] mbases     Σ length of M/=/X ops        (what count_coverage adds for a fully covered record,
+ *                                                 infer_breakpoint_graph.py:131, :1033)
+ *   [1] qinfer     Σ length of M/I/S/H/=/X ops  (pysam infer_read_length(), :1031)
+ *   [2] blk_first  start of the first aligned block, [3] blk_last end of the last one (-1: none)
+ *                                                (blocks[0][0], blocks[-1][1] at :760)
+ * and one row (record, op index of the next block, prev block end, next block start) is appended to
  * `gaps` for every pair of consecutive blocks further apart than `min_gap` in a record with
  * mapq >= min_mapq (:754, :757-758).  *gap_count is a device counter the caller zeroes beforehand;
- * rows beyond gap_cap are dropped (the counter still counts them).
+ * rows beyond gap_cap are dropped (the counter still counts them).  summary and gaps must be 16-byte aligned.
  * ------------------------------------------------------------------------------------------------ */
-int coral_cigar_scan(const coral_records_t *rec, int32_t min_gap, int32_t min_mapq,
-                     int32_t *mbases, int32_t *qinfer, int32_t *blk_first, int32_t *blk_last,
-                     int32_t *gaps /* [gap_cap][4] */, uint32_t *gap_count, uint32_t gap_cap,
-                     void *stream);
+int coral_cigar_scan(const coral_records_t *rec, int32_t min_gap, int32_t min_mapq, int32_t *summary /* [n_rec][4] */,
+                     int32_t *gaps /* [gap_cap][4] */, uint32_t *gap_count, uint32_t gap_cap, void *stream);
+/* Name of the kernel behind coral_cigar_scan as rocprofv3 prints it (reported next to the roofline figures). */
+const char *coral_scan_kernel_name(void);
 
 /* ------------------------------------------------------------------------------------------------
  * coral_segment_coverage — per-segment record count and aligned-base count.
@@ -85,11 +85,11 @@ int coral_cigar_scan(const coral_records_t *rec, int32_t min_gap, int32_t min_ma
  *   n_bases[j] = Σ of the four pysam count_coverage arrays with quality_threshold=0,
  *                read_callback='nofilter' BEFORE the non-ACGT correction (:130-132, :1033-1034):
  *                aligned (M/=/X) bases of records with SEQ that fall inside the segment.
- * Records fully inside one segment use mbases[] from coral_cigar_scan; only records straddling a
+ * Records fully inside one segment use the `summary` rows of coral_cigar_scan; only records straddling a
  * segment boundary have their CIGAR walked again.  n_reads / n_bases are ADDED to (caller zeroes).
  * `strad` is a workspace of n_rec uint32 and `strad_count` a zeroed device counter.
  * ------------------------------------------------------------------------------------------------ */
-int coral_segment_coverage(const coral_records_t *rec, const int32_t *mbases, const int32_t *qinfer,
+int coral_segment_coverage(const coral_records_t *rec, const int32_t *summary /* [n_rec][4] */,
                            int32_t n_seg, const int32_t *seg_tid, const int32_t *seg_start,
                            const int32_t *seg_end, unsigned long long *n_reads,
                            unsigned long long *n_bases, uint32_t *strad, uint32_t *strad_count,
@@ -217,26 +217,6 @@ int coral_search_result(void *handle, int64_t *n_meta, const int64_t **meta, int
  * ------------------------------------------------------------------------------------------------ */
 int coral_read_counter(const uint32_t *dev_counter, uint32_t *host_value, void *stream);
 
-/* Launch-duration probe used by bench.py: runs `fn` = coral_cigar_scan `iters` times between two HIP
- * events recorded on `stream` (the stream the kernel is launched on) and returns the mean duration of
- * one launch in milliseconds in *ms_per_launch. */
-int coral_time_cigar_scan(const coral_records_t *rec, int32_t min_gap, int32_t min_mapq,
-                          int32_t *mbases, int32_t *qinfer, int32_t *blk_first, int32_t *blk_last,
-                          int32_t *gaps, uint32_t *gap_count, uint32_t gap_cap, int32_t iters,
-                          float *ms_per_launch, void *stream);
-
-/* Tuning hooks for A/B measurements: variant 1 = first cigar_scan kernel; 2 / 3 / 4 = batched prefetching DPP kernel
- * with 4 / 8 (default) / 2 KiB per wave in flight; 5 = diagnostic (loads only, no arithmetic, outputs invalid);
- * 6 = "flat" kernel (each wave streams a contiguous range of whole records); 7 = variant 3 with a conservative per-chunk
- * filter in front of the exact gap search; 8-14 = packed / in-place-ring experiments; 15 (default) / 16 / 17 / 18 = variant 7
- * with tiles of 8 / 32 / 4 / 16 consecutive records per wave; 19 = tiled diagnostic (loads only); 20-27 = further
- * measured alternatives (tile stream, unmasked full-chunk loads, other batch sizes; profiles/r01_scan_variants.md).  coral_time_stream_read times a plain
- * grid-stride 16-byte-per-lane read of n_words uint32 (the ceiling for a kernel that touches every op once). */
-int coral_set_scan_variant(int variant);
-int coral_set_probe_mode(int mode);   /* 1 = grid-stride probe, 2 = one contiguous region per wave */
-int coral_time_stream_read(const uint32_t *cigar, long long n_words, uint32_t *scratch, int iters, float *ms,
-                           void *stream);
-
 /* ------------------------------------------------------------------------------------------------
  * coral_cluster_first_fit — HOST function (no device work).
  *
@@ -332,6 +312,21 @@ int coral_bam_decode_fill(void *handle, int32_t *tid, int32_t *pos, int32_t *end
                           int64_t *nonacgt_rec, int32_t *nonacgt_pos, char *names, char *ref_names,
                           int32_t *ref_lens);
 int coral_bam_decode_close(void *handle);
+/* The same for the rank-th of `world` byte ranges of the file (one process per GPU decodes only its share): the range starts
+ * at the first BGZF block at or after its first byte and at the first record that starts in that block's inflated bytes or
+ * later, and ends with the record that straddles into the next range; read-name ids are local to the range. */
+int coral_bam_decode_range(const char *path, int32_t n_threads, int32_t rank, int32_t world, void **handle);
+/* stats = compressed bytes, uncompressed bytes, BGZF blocks of the decoded range; *seconds = wall time of the decode. */
+int coral_bam_decode_stats(void *handle, int64_t stats[3], double *seconds);
+/* SoA records -> coordinate-sorted BAM (tests and benchmarks only; the product reads BAM).  Arrays as coral_bam_decode_fill
+ * delivers them (names / ref_names: one C string per name id / contig); SEQ is hash-made ACGT with N at the listed aligned
+ * positions, QUAL absent, tags NM:i, SA:Z, and CG:B,I for CIGARs of more than 65535 operations. */
+int coral_bam_write(const char *path, int64_t n_rec, const int32_t *tid, const int32_t *pos, const int32_t *flag,
+                    const int32_t *mapq, const int32_t *qlen, const int32_t *has_seq, const int32_t *nm, const int32_t *name_id,
+                    const int32_t *n_cigar, const int64_t *cigar_off, const uint32_t *cigar, const int64_t *sa_off,
+                    const int32_t *sa, const int32_t *sa_nm, int64_t n_nonacgt, const int64_t *nonacgt_rec,
+                    const int32_t *nonacgt_pos, const char *const *names, int32_t n_ref, const char *const *ref_names,
+                    const int32_t *ref_lens, uint32_t seed, int32_t level, int32_t n_threads);
 const char *coral_bam_last_error(void);
 
 #ifdef __cplusplus

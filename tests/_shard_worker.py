@@ -26,7 +26,17 @@ def main():
     cn, seeds = os.path.join(outdir, "cn%d.bed" % rank), os.path.join(outdir, "seeds%d.bed" % rank)
     synth.write_cn_bed(cfg, cn)
     synth.write_seed_bed(cfg, seeds)
-    dr = sharding.shard_records(rec, rank, world, "cpu")
+    if len(sys.argv) > 3:          # per-rank input: every rank decodes only its byte range of the BAM written by the test
+        dr = sharding.load_bam_sharded(sys.argv[3], rank, world, "cpu", n_threads=2)
+        assert dr.has_host == (rank == 0)
+        if rank == 0:           # unified read-name ids = first appearance over the whole file, as a one-process decode numbers them
+            want = rec.materialise_names()
+            ids = rec.name_id.tolist()
+            assert [dr.names[i] for i in dr.h_name_id.tolist()] == [want[i] for i in ids]
+            first_seen = list(dict.fromkeys(want[i] for i in ids))
+            assert dr.names == first_seen
+    else:
+        dr = sharding.shard_records(rec, rank, world, "cpu")
     assert 0 < dr.n < dr.n_total
     b = sharding.build_graph_sharded(dr, seeds, cn, os.path.join(outdir, "sh") if rank == 0 else None)
     if rank == 0:

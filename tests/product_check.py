@@ -186,22 +186,22 @@ def install_cpu_kernel_fakes(monkeypatch):
     def scan_local(dr, min_gap, min_mapq, gap_cap):
         h = host_of(dr)
         mb, qi, b0, b1, rows = [], [], [], [], []
-        for i in range(dr.lo, dr.hi):
+        for i in range(dr.lo - dr._rec_offset, dr.hi - dr._rec_offset):        # ordinals within dr._rec
             bl = h.blocks(i)
             mb.append(sum(e - s for s, e in bl)); qi.append(h.infer_read_length(i) or 0)
             b0.append(bl[0][0] if bl else -1); b1.append(bl[-1][1] if bl else -1)
             if h.mapq[i] >= min_mapq:
                 for k in range(len(bl) - 1):
                     if abs(bl[k + 1][0] - bl[k][1]) > min_gap:
-                        rows.append((i - dr.lo, k + 1, bl[k][1], bl[k + 1][0], b0[-1], b1[-1]))
-        t = lambda x: torch.tensor(x, dtype=torch.int32)
-        return t(mb), t(qi), t(b0), t(b1), lambda: torch.tensor(rows, dtype=torch.int64).reshape(-1, 6)
+                        rows.append((i + dr._rec_offset - dr.lo, k + 1, bl[k][1], bl[k + 1][0], b0[-1], b1[-1]))
+        summary = torch.tensor([mb, qi, b0, b1], dtype=torch.int32).t().contiguous().reshape(-1, 4)
+        return summary, lambda: torch.tensor(rows, dtype=torch.int64).reshape(-1, 6)
 
     def coverage_local(dr, scan, sg):
         h = host_of(dr)
         out = torch.zeros((2, len(sg)), dtype=torch.int64)
         for j, (t, s, e) in enumerate(sg):
-            idx = [i for i in h.region(h.chroms[t], s, e) if dr.lo <= i < dr.hi]
+            idx = [i for i in h.region(h.chroms[t], s, e) if dr.lo <= i + dr._rec_offset < dr.hi]
             out[0, j] = sum(1 for i in idx if h.infer_read_length(i))
             tot = 0
             for i in idx:
@@ -214,13 +214,22 @@ def install_cpu_kernel_fakes(monkeypatch):
         h = host_of(dr)
         keys = []
         for j, (t, p) in enumerate(uniq):
-            keys += [(j << 32) | (int(i) - dr.lo) for i in h.region(h.chroms[t], p, p + 1) if dr.lo <= i < dr.hi]
+            keys += [(j << 32) | (int(i) + dr._rec_offset - dr.lo) for i in h.region(h.chroms[t], p, p + 1)
+                     if dr.lo <= i + dr._rec_offset < dr.hi]
         return torch.tensor(keys, dtype=torch.int64)
 
     def sa_table_local(dr):
         """coral_sa_table stand-in: the oracle's fetch() (string SA entries, per-read Python lists) turned into arrays."""
         from oracle import coral_oracle as O
-        h = host_of(dr)
+
+        class _WholeFile:          # the host mirrors of the whole file (the product builds the SA table from them too)
+            n, header_chroms = dr.n_total, dr.header_chroms
+            tid, pos, end, flag, mapq, qlen, has_seq, nm = dr.h_tid, dr.h_pos, dr.h_end, dr.h_flag, dr.h_mapq, dr.h_qlen, dr.h_has_seq, dr.h_nm
+            name_id, n_cigar, sa_off, sa, sa_nm = dr.h_name_id, dr.h_n_cigar, dr.h_sa_off, dr.h_sa, dr.h_sa_nm
+            cigar_off, cigar = np.zeros(dr.n_total + 1, dtype=np.int64), np.zeros(0, dtype=np.int32)
+            nonacgt_rec, nonacgt_pos = dr.h_nonacgt_rec, dr.h_nonacgt_pos
+            materialise_names = staticmethod(lambda: dr.names)
+        h = HostRecords(_WholeFile)
         ob = O.OracleGraphBuild.__new__(O.OracleGraphBuild)
         ob.rec, ob.read_length, ob.chimeric_alignments, ob.nm_stats = h, {}, {}, [0.0, 0.0, 0]
         ob.fetch()

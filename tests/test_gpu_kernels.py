@@ -6,7 +6,6 @@ import torch
 from coral_amd import synth
 
 pytestmark = pytest.mark.gpu
-DEFAULT_VARIANT = 15          # the library default (coral_kernels.hip: g_scan_variant)
 
 
 def _odd_records():
@@ -79,17 +78,12 @@ def case(request):
     return request.param, rec, HostRecords(rec), DeviceRecords(rec, "cuda:0")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 21, 22, 23, 25, 26, 27])
-def test_cigar_scan(case, variant):
-    """Every variant of the scan kernel (first version, batched per-record 2/4/8 KiB, flat contiguous ranges, and the
-    8 KiB one with the conservative per-chunk gap filter)."""
-    from coral_amd import kernels, _lib
+def test_cigar_scan(case):
+    """coral_cigar_scan (flat balanced stream through an LDS ring, record boundaries handled per piece) against the oracle's
+    per-record blocks: sums, first / last block, every large gap in the reference's order."""
+    from coral_amd import kernels
     name, rec, host, dr = case
-    assert _lib.lib().coral_set_scan_variant(variant) == 0
-    try:
-        res = kernels.cigar_scan(dr, 600, 20, gap_cap=64)       # small cap: exercises the overflow/retry path
-    finally:
-        _lib.lib().coral_set_scan_variant(DEFAULT_VARIANT)
+    res = kernels.cigar_scan(dr, 600, 20, gap_cap=64)       # small cap: exercises the overflow/retry path
     mb, qi = res.mbases.cpu().numpy(), res.qinfer.cpu().numpy()
     b0, b1 = res.blk_first.cpu().numpy(), res.blk_last.cpu().numpy()
     gaps = []
@@ -111,21 +105,16 @@ def test_cigar_scan(case, variant):
         assert len(gaps) == 5     # a, b(N), e, i x2
 
 
-@pytest.mark.parametrize("variant", [7, 13, 15, 20])
 @pytest.mark.parametrize("min_gap", [0, 1, 3, 299, 300, 301, 601, 1199, 5000])
-def test_cigar_scan_gap_filter_thresholds(min_gap, variant):
-    """The filtered variant against the oracle's blocks for thresholds around the D/N lengths of the adversarial set
+def test_cigar_scan_gap_filter_thresholds(min_gap):
+    """The conservative gap filter against the oracle's blocks for thresholds around the D/N lengths of the adversarial set
     (odd and even: the filter flags a lane at G > min_gap // 2)."""
-    from coral_amd import kernels, _lib
+    from coral_amd import kernels
     from coral_amd.records import DeviceRecords
     from oracle.hostrecords import HostRecords
     rec = _adversarial_records(seed=17 + min_gap, n=120)
     host, dr = HostRecords(rec), DeviceRecords(rec, "cuda:0")
-    assert _lib.lib().coral_set_scan_variant(variant) == 0
-    try:
-        res = kernels.cigar_scan(dr, min_gap, 20)
-    finally:
-        _lib.lib().coral_set_scan_variant(DEFAULT_VARIANT)
+    res = kernels.cigar_scan(dr, min_gap, 20)
     want = []
     for i in range(host.n):
         bl = host.blocks(i)
@@ -135,6 +124,43 @@ def test_cigar_scan_gap_filter_thresholds(min_gap, variant):
         assert int(res.mbases[i]) == sum(e - s for s, e in bl)
     assert [(int(g[0]), int(g[2]), int(g[3])) for g in res.gaps] == want
     assert len(want) > 50 or min_gap >= 1199
+
+
+def test_cigar_scan_record_shapes():
+    """Records the flat stream has to cut correctly: many records inside one 1 KiB chunk, records without any op between
+    records with ops, single-quad records, a record of exactly 64 / 128 quads (chunk-aligned ends), one far longer than the
+    ring (> 8 KiB of ops), all next to each other and at both ends of the file."""
+    from coral_amd import kernels
+    from coral_amd.records import DeviceRecords
+    from oracle.hostrecords import HostRecords
+    M, I, D, N, S, H, P, EQ, X = range(9)
+    rng = np.random.default_rng(3)
+    alns, pos = [], 50
+
+    def add(ops, **kw):
+        nonlocal pos
+        alns.append(dict(tid=0, pos=pos, cigar=ops, name="s%d" % len(alns), **kw))
+        pos += 7
+    add([], flag=4, has_seq=1, qlen=30)                                      # file starts with an op-less record
+    for n_ops in (1, 2, 3, 4, 5, 8, 1, 1, 1, 255, 256, 257, 511, 512, 513, 3, 4):
+        add([((M, D)[k % 2], 1 + int(rng.integers(0, 700 if k % 2 else 9))) for k in range(n_ops)])
+    add([], flag=4)
+    add([], flag=4)
+    add([(M, 3), (D, 900), (M, 3)] * 1200)                                   # 3600 ops = 14 KiB: longer than the ring, many gaps
+    for _ in range(40):                                                      # a burst of tiny records: dozens per chunk
+        add([(M, int(rng.integers(1, 20)))] + ([(D, 650), (M, 2)] if rng.random() < 0.3 else []))
+    add([], flag=4)                                                          # and ends with one
+    rec = synth.records_from_alignments(alns)
+    host, dr = HostRecords(rec), DeviceRecords(rec, "cuda:0")
+    res = kernels.cigar_scan(dr, 600, 20)
+    want = []
+    for i in range(host.n):
+        bl = host.blocks(i)
+        assert int(res.mbases[i]) == sum(e - s for s, e in bl), i
+        assert int(res.qinfer[i]) == (host.infer_read_length(i) or 0), i
+        assert (int(res.blk_first[i]), int(res.blk_last[i])) == ((bl[0][0], bl[-1][1]) if bl else (-1, -1)), i
+        want += [(i, bl[k][1], bl[k + 1][0]) for k in range(len(bl) - 1) if bl[k + 1][0] - bl[k][1] > 600]
+    assert [(int(g[0]), int(g[2]), int(g[3])) for g in res.gaps] == want and len(want) > 1200
 
 
 def _random_segments(host, rng, n):
