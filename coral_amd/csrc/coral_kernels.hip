@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/coral_hip.h"
@@ -20,6 +21,8 @@ typedef uint32_t cquad_t __attribute__((ext_vector_type(4)));   // one 16-byte C
 #define MASK_REF 0x18Du   // M D N = X advance the reference
 #define MASK_ALN 0x181u   // M = X are aligned blocks (pysam get_blocks / count_coverage)
 #define MASK_QRY 0x1B3u   // M I S H = X count towards infer_read_length()
+#define MASK_DN 0x00Cu    // D N: advance the reference without being aligned (what a gap is made of)
+#define MASK_ISH 0x032u   // I S H: count towards infer_read_length() without being aligned
 
 static thread_local char g_err[512] = "";
 
@@ -77,28 +80,27 @@ __device__ __forceinline__ int wave_sum_dpp(int x) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1  k_cigar_scan_v3 — the fused CIGAR pass (production kernel of coral_cigar_scan).
+// K1  k_cigar_scan_v4 — the fused CIGAR pass (production kernel of coral_cigar_scan).
 //
 // Per alignment record: Σ aligned bases, infer_read_length, first / last aligned block, and every gap > min_gap between
 // consecutive aligned blocks (the get_blocks() walk of /root/reference/src/infer_breakpoint_graph.py:750-762 plus the
 // per-record sums count_coverage / infer_read_length need, ibg:131, :1031-1034).  HBM-bound: 4 bytes per CIGAR op, read once.
 //
-// Structure (what round 1's measurements asked for: profiles/r01_scan_variants.md, profiles/r02_scan.md):
-//   * FLAT STREAM, BALANCED.  The op array of all records is one contiguous stream of 16-byte quads (records are padded to whole
-//     quads).  Wave w owns the records whose first quad falls into the w-th of n_waves equal slices of that stream (found with a
-//     64-ary cooperative search of cigar_off), so every wave streams the same number of bytes (± one record), all waves are
-//     resident at once (grid = what fits the chip) and nothing is left for a second round of workgroups.
-//   * LDS RING FED BY LDS-DMA.  Each wave keeps RING KiB in flight with global_load_lds_dwordx4 (1 KiB per instruction, no VGPR
-//     destination): full, unmasked, 128-byte-aligned loads that ignore record boundaries; one counted s_waitcnt vmcnt(RING - 1)
-//     per chunk retires the oldest slot, the lane reads its quad with one ds_read_b128, and the slot is refilled at once.  Data
-//     costs no registers, so occupancy is set by LDS (RING KiB per wave), not by a 64-VGPR double buffer.
-//   * RECORD BOUNDARIES IN THE ARITHMETIC.  A chunk that lies inside one record (6 of 7 at 20 kb reads) takes the single-piece
-//     path; otherwise it is processed once per record piece with the other lanes masked to padding (op 15 consumes nothing).
-//   * The arithmetic per piece is round 1's: branch-free class lookup (v_bfe_i32 with the op word as bit offset), DPP add-scan
-//     for the reference offsets, and the conservative gap filter — only pieces that can hold a gap > min_gap run the exact
-//     max-scan + distance tests (see `scan_piece`).
-//   * SUMMARIES LEAVE IN 1 KiB STORES.  The four per-record results are one 16-byte row; rows are parked in LDS and written 64
-//     at a time as one coalesced store (round 1 wrote four scattered 4-byte words per record: 7.3 x write amplification).
+// Structure (what the measurements asked for: profiles/r01_scan_variants.md, profiles/r02_scan.md):
+//   * ONE MOVING WINDOW.  The op array of all records is one contiguous stream of 16-byte quads (records are padded to whole
+//     quads).  Work is handed out in groups of consecutive records from a cursor, to as many waves as are resident at once
+//     (grid = what fits the chip): all waves read close to each other and the window moves through the array front to back.
+//   * STATIC REGISTER RING.  RING quads per lane, loop unrolled by RING so that no quad is ever moved: while a chunk (64 lanes x
+//     16 bytes = 1 KiB) is processed, the next RING - 1 are in flight as full, 128-byte-aligned global_load_dwordx4 that ignore
+//     record boundaries (scalar base + per-lane offset, non-temporal), retired by counted waits.  An LDS ring fed by LDS-DMA
+//     was measured slower (lab/coral_scan_v3_ldsdma.hip.inc).
+//   * LANE-LOCAL FAST PATH.  A chunk in which every lane holds an aligned op and at most min_gap / 2 of D / N cannot end a
+//     reportable gap, and the three per-record sums are order-free: such a chunk costs ~45 VALU instructions and no cross-lane
+//     step.  Record boundaries inside such a chunk are lane masks; the wave-level sums run once per RECORD, not per chunk.
+//     Only flagged chunks (and the one after a flagged last lane) take the exact scan (`scan_piece`: DPP add-scan for the
+//     reference offsets, max-scan + distance tests for the gaps), once per record piece, outside the pipelined loop.
+//   * SUMMARIES LEAVE AS FULL LINES.  The four per-record results are one 16-byte row; rows are parked in LDS and written per
+//     group as one coalesced store (round 1 wrote four scattered 4-byte words per record: 7.3 x write amplification).
 // ---------------------------------------------------------------------------------------------
 struct ScanState {
     int carry_ref, carry_end, msum, qsum, first;
@@ -233,111 +235,270 @@ __device__ __forceinline__ long long first_record_at(const int64_t *__restrict__
     return m == 0ull ? hi : lo + (long long)__builtin_ctzll(m);
 }
 
-// LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to the wave-uniform LDS byte address `lds_dst` (+ lane * 16).
-// M0 carries the LDS base and is compiler-reserved: save / set / restore inside the one statement (guide: cdna_hip_programming.md §10).
-__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+// One 1 KiB wave load (64 lanes x 16 bytes, non-temporal) that the compiler does NOT track: the scan kernel keeps a fixed number
+// of them in flight and retires them with its own counted waits (`ring_wait`), because the compiler's wait insertion falls back
+// to vmcnt(0) at the loop's exit latch.  Every such load must be retired (`ring_wait<0>`) before its register can be reused.
+__device__ __forceinline__ void ring_load(cquad_t &q, const char *wave_uniform_base, uint32_t lane_off) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(q) : "v"(lane_off), "s"(wave_uniform_base) : "memory");
+}
+template <int OUTSTANDING>
+__device__ __forceinline__ void ring_wait(cquad_t &q) {          // q is valid once at most OUTSTANDING younger loads are in flight
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(q) : "n"(OUTSTANDING) : "memory");
 }
 
+// What the fast path keeps per lane between two exact positions: the sums are lane-local (no wave scan per chunk).
+//   position of the next op of the record = st.carry_ref + wave_sum(ref_lane)
 template <int RING>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v3(
+__global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v4(
     long long n_rec, const int32_t *__restrict__ pos, const int32_t *__restrict__ flagmq,
     const int64_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar, int min_gap, int min_mapq,
-    int4 *__restrict__ summary, int32_t *__restrict__ gaps, uint32_t *__restrict__ gap_count, uint32_t gap_cap) {
-    __shared__ cquad_t lds[SCAN_BLOCK / WAVE][RING + 1][WAVE];        // per wave: RING slots of 1 KiB + 1 KiB of parked summaries
+    int4 *__restrict__ summary, int32_t *__restrict__ gaps, uint32_t *__restrict__ counters, uint32_t gap_cap, int group) {
+    uint32_t *__restrict__ gap_count = counters;
+    __shared__ int4 park_all[SCAN_BLOCK / WAVE][WAVE];           // per wave: 1 KiB of parked summaries
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long wave = (long long)blockIdx.x * (SCAN_BLOCK / WAVE) + wib;
     const long long nwaves = (long long)gridDim.x * (SCAN_BLOCK / WAVE);
     const cquad_t pad = {OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD};
-    const cquad_t *__restrict__ qbase = reinterpret_cast<const cquad_t *>(cigar);
 
-    // ---- this wave's records: those whose first quad lies in the wave-th of nwaves equal slices of the quad stream
+    // ---- work: groups of `group` consecutive records.  The first two groups of a wave are static (wave, wave + nwaves), later
+    // ones come from the work cursor (counters[1], zero on entry).  All resident waves therefore stream one compact window of
+    // the op array that moves through it front to back (measured at cfg3: 2.7 ms, against 3.5 ms when every wave walks its own
+    // 1 / nwaves slice of the array), and the dynamic hand-out levels the unequal record lengths.  One cursor serves ~80 M
+    // requests / s (measured), which is why a group is 24 records and not 4.  Group ids are known two rounds ahead and the
+    // bounds of the next group are loaded while the current one is processed: a group change costs no dependent round trip.
     const long long total_q = cigar_off[n_rec] >> 2;
-    const long long ra = wave == 0 ? 0 : first_record_at(cigar_off, n_rec, 4 * ((total_q * wave) / nwaves), lane);
-    const long long rb = wave == nwaves - 1 ? n_rec : first_record_at(cigar_off, n_rec, 4 * ((total_q * (wave + 1)) / nwaves), lane);
-    if (ra >= rb) return;                                        // (wave-uniform)
-    const long long s0 = cigar_off[ra] >> 2, s1 = cigar_off[rb] >> 2;      // quad range of the wave
-    const long long base = s0 & ~7ll;                            // loads start on a 128-byte line
-    const long long n_chunks = (s1 - base + WAVE - 1) / WAVE;    // may be 0 (only empty records)
-    const uint32_t lds_wave = (uint32_t)(uintptr_t)&lds[wib][0][0];       // LDS byte address of the wave's ring
-
-    auto issue = [&](long long c) {                              // chunk c -> slot c % RING; never reads past the stream's end
-        const long long q = base + c * WAVE + lane;
-        if (q < total_q) glds16(qbase + q, lds_wave + (uint32_t)(c % RING) * (WAVE * 16));
+    const int last_rec = (int)n_rec - 1;                         // n_rec < 2^31
+    const int n_groups = (int)((n_rec + group - 1) / group);
+    const int dyn_base = 2 * (int)nwaves;                        // first group id the cursor hands out
+    int g = (int)wave, g_next = (int)(wave + nwaves);
+    long long nx_s0, nx_s1, nx_e0;                               // cigar_off[first], [end], [first + 1] of the group about to start
+    int nx_pos, nx_fm;
+    auto request_group = [&](int gg) {                           // (clamped: valid loads for any gg)
+        const long long a = (long long)gg * group, e = a + group;
+        const int first = a < n_rec ? (int)a : (int)n_rec, end = e < n_rec ? (int)e : (int)n_rec;
+        nx_s0 = cigar_off[first];
+        nx_s1 = cigar_off[end];
+        nx_e0 = cigar_off[first < (int)n_rec ? first + 1 : first];
+        nx_pos = pos[first < last_rec ? first : last_rec];
+        nx_fm = flagmq[first < last_rec ? first : last_rec];
     };
-    for (long long c = 0; c < RING && c < n_chunks; ++c) issue(c);
+    request_group(g);
+    while (g < n_groups) {
+    unsigned ticket = 0;
+    if (lane == 0) ticket = atomicAdd(counters + 1, 1u);
+    const int ra = g * group;
+    const int rb = ra + group < (int)n_rec ? ra + group : (int)n_rec;
+    const long long s0 = nx_s0 >> 2, s1 = nx_s1 >> 2;            // quad range of the group
+    const long long e0 = nx_e0 >> 2;
+    const int first_pos = nx_pos, first_fm = nx_fm;
+    request_group(g_next);
+    const long long base = s0 & ~7ll;                            // loads start on a 128-byte line
+    const int n_chunks = (int)((s1 - base + WAVE - 1) / WAVE);   // may be 0 (only empty records)
 
-    // ---- record cursor (metadata is wave-uniform: scalar loads, requested one record ahead)
-    long long r = ra;
-    long long rec_start = s0, rec_end = cigar_off[ra + 1] >> 2;
-    int p0 = pos[ra];
-    bool gaps_on = ((flagmq[ra] >> 16) & 0xff) >= min_mapq;
-    const long long last_rec = n_rec - 1;
+    // ---- loads: full 1 KiB chunks that ignore record boundaries, wave-uniform base + per-lane byte offset; only the lanes of
+    // the stream's very last chunk are clamped (they re-read the last quad and are masked out as "not in any record")
+    const char *wave_src = reinterpret_cast<const char *>(cigar) + base * 16;
+    const long long room_bytes = (total_q - base) * 16 - 16;     // largest valid byte offset of a quad load from wave_src
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    auto lane_offset = [&](int c) -> uint32_t {                  // the lane's byte offset inside chunk c, clamped to the stream's end
+        const long long room = room_bytes - (long long)c * (WAVE * 16);          // >= 0 for every chunk of the wave
+        const uint32_t lim = (room >> 31) != 0 ? 0x7fffffffu : (uint32_t)room;
+        return lane_off < lim ? lane_off : lim;
+    };
+    auto load = [&](int c) -> cquad_t {                          // compiler-tracked (exact path)
+        return __builtin_nontemporal_load(reinterpret_cast<const cquad_t *>(wave_src + (long long)c * (WAVE * 16) + lane_offset(c)));
+    };
+
+    // ---- record cursor (metadata is wave-uniform: scalar loads, requested one record ahead); positions relative to `base`
+    int r = ra;
+    int rec_start = (int)(s0 - base), rec_end = (int)(e0 - base);
+    int p0 = first_pos;
+    bool gaps_on = ((first_fm >> 16) & 0xff) >= min_mapq;
     long long n_end = 0;
     int n_pos = 0, n_fm = 0;
-    auto request = [&](long long rr) {                           // unconditional (clamped) loads: no select on the loaded value
-        const long long c = rr < n_rec ? rr : last_rec;
+    auto request = [&](int rr) {                                 // unconditional (clamped) loads: no select on the loaded value
+        const int c = rr <= last_rec ? rr : last_rec;
         n_end = cigar_off[c + 1];
         n_pos = pos[c];
         n_fm = flagmq[c];
     };
     request(ra + 1);
     ScanState st = {0, 0, 0, 0, 0, false};
+    int ref_lane = 0;                                            // (per lane) reference advance of the fast chunks since the last sync
+    bool dirty = false;                                          // ref_lane != 0 somewhere: st.carry_ref / st.carry_end are behind
+    bool have_first = false;                                     // the record's first aligned block is known (st.first)
     const int half_gap = min_gap >> 1;
     int parked = 0;                                              // summaries waiting in LDS (wave-uniform)
-    int4 *park = reinterpret_cast<int4 *>(&lds[wib][RING][0]);
+    int4 *park = &park_all[wib][0];
+    // make st.carry_ref / st.carry_end exact again at the start of chunk c.  While dirty, the previous chunk belongs to the
+    // current record and its last lane holds an aligned op: the D / N ops behind that op (normally none) are read back with
+    // one scalar load instead of being tracked per chunk.
+    auto sync_at = [&](int c) {
+        if (dirty) {
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(wave_src) + ((long long)c * WAVE - 1) * 4;
+            int trail = 0;
+            bool open = true;
+#pragma unroll
+            for (int k = 3; k >= 0; --k) {
+                const uint32_t x = w[k];
+                open = open && ((MASK_ALN >> (x & 15u)) & 1u) == 0u;
+                if (open && ((MASK_REF >> (x & 15u)) & 1u)) trail += (int)(x >> 4);
+            }
+            st.carry_ref += wave_sum_dpp(ref_lane);
+            st.carry_end = st.carry_ref - trail;
+            ref_lane = 0;
+            dirty = false;
+        }
+    };
     auto flush = [&]() {                                         // `parked` rows -> summary[r - parked .. r)
         if (lane < parked) summary[r - parked + lane] = park[lane];
         parked = 0;
     };
-    auto finish_record = [&]() {
+    auto emit = [&](int first_out, int end_out) {                // the current record is complete
         const int ms = wave_sum_dpp(st.msum);
         const int qs = wave_sum_dpp(st.qsum);
-        if (lane == 0) park[parked] = make_int4(ms, qs, st.carry_end > 0 ? p0 + st.first : -1, st.carry_end > 0 ? p0 + st.carry_end : -1);
+        if (lane == 0) park[parked] = make_int4(ms, qs, first_out, end_out);
         ++parked;
         st = {0, 0, 0, 0, 0, false};
+        ref_lane = 0;
+        dirty = false;
+        have_first = false;
         ++r;
         if (parked == WAVE) flush();
         rec_start = rec_end;
-        rec_end = n_end >> 2;
+        rec_end = (int)((n_end >> 2) - base);
         p0 = n_pos;
         gaps_on = ((n_fm >> 16) & 0xff) >= min_mapq;
         request(r + 1);
     };
+    auto finish_record = [&]() {                                 // exact state (not dirty)
+        emit(st.carry_end > 0 ? p0 + st.first : -1, st.carry_end > 0 ? p0 + st.carry_end : -1);
+    };
 
-    for (long long c = 0; c < n_chunks; ++c) {
-        // retire the oldest slot: with RING loads in flight, at most RING - 1 may remain (the tail of the range simply drains)
-        if (c + RING <= n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING - 1) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        cquad_t quad = lds[wib][c % RING][lane];
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(quad)::"memory");        // the read has landed: its slot may be refilled
-        if (c + RING < n_chunks) issue(c + RING);
-        const long long cq0 = base + c * WAVE, cq1 = cq0 + WAVE;
-        if (rec_start <= cq0 && rec_end > cq1) {                 // (wave-uniform) the chunk lies inside the current record
-            scan_piece(quad, lane, st, gaps_on, min_gap, half_gap, (int)r, (int)(cq0 - rec_start), p0, gaps, gap_count, gap_cap);
-            continue;
+    // ---- fast chunk: returns false (state untouched) when the chunk needs the exact path.
+    // Per-lane sums of the four ops; flags as in scan_piece: a lane without aligned op, or with more than min_gap / 2 of
+    // D / N — then (and after a flagged last lane) the chunk is not fast.
+    auto fast = [&](const cquad_t quad, const int c) __attribute__((always_inline)) -> bool {
+        const int cq0 = c * WAVE, cq1 = cq0 + WAVE;
+        int fal[4], radv[4];
+        int asum = 0, rsum = 0, qsum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t w = quad[k];
+            const int len = (int)(w >> 4);
+            fal[k] = __builtin_amdgcn_sbfe((int)(MASK_ALN * 0x10001u), w, 1u);
+            radv[k] = len & __builtin_amdgcn_sbfe((int)(MASK_REF * 0x10001u), w, 1u);
+            asum += len & fal[k];
+            rsum += radv[k];
+            qsum += len & __builtin_amdgcn_sbfe((int)(MASK_QRY * 0x10001u), w, 1u);
         }
-        const long long lq = cq0 + lane;
+        const int m3 = fal[3], m2 = m3 | fal[2], m1 = m2 | fal[1], m0 = m1 | fal[0];
+        const unsigned long long flagged = __ballot(m0 == 0) | __ballot(rsum - asum > half_gap);
+        if (flagged != 0ull || st.tail_flagged || !(have_first || rec_start >= cq0)) return false;      // (wave-uniform)
+        if (rec_start <= cq0 && rec_end > cq1) {                 // inside one record: lane-local sums only
+            st.msum += asum;
+            st.qsum += qsum;
+            ref_lane += rsum;
+            dirty = true;
+            return true;
+        }
+        // ---- a chunk with record boundaries and nothing flagged: every lane holds an aligned op, no gap can be reported;
+        // a record starting here has its first block in its first lane, one ending here has its last block in its last lane
+        const int n0 = ~fal[0], n1 = n0 & ~fal[1], n2 = n1 & ~fal[2];
+        const int lf = (radv[0] & n0) + (radv[1] & n1) + (radv[2] & n2);          // reference advance before the lane's first aligned op
+        const int lt = (radv[3] & ~m3) + (radv[2] & ~m2) + (radv[1] & ~m1);       // ... behind the lane's last aligned op
         while (r < rb) {                                         // once per record present in this chunk
-            const long long a = rec_start > cq0 ? rec_start : cq0, b = rec_end < cq1 ? rec_end : cq1;
+            const int a = (rec_start > cq0 ? rec_start : cq0) - cq0, b = (rec_end < cq1 ? rec_end : cq1) - cq0;
             if (b > a) {
-                cquad_t piece = pad;
-                if (lq >= a && lq < b) piece = quad;
-                scan_piece(piece, lane, st, gaps_on, min_gap, half_gap, (int)r, (int)(cq0 - rec_start), p0, gaps, gap_count, gap_cap);
+                const bool in = (unsigned)(lane - a) < (unsigned)(b - a);
+                if (rec_start >= cq0) {                          // the record starts in this chunk (st.carry_ref == 0)
+                    st.first = __builtin_amdgcn_readlane(lf, a);
+                    have_first = true;
+                }
+                st.msum += in ? asum : 0;
+                st.qsum += in ? qsum : 0;
+                ref_lane += in ? rsum : 0;
+                dirty = true;
             }
             if (rec_end > cq1) break;                            // the record continues in the next chunk
-            finish_record();
+            if (have_first) {
+                const int end = st.carry_ref + wave_sum_dpp(ref_lane) - (b > a ? __builtin_amdgcn_readlane(lt, b - 1) : 0);
+                emit(p0 + st.first, p0 + end);
+            } else {
+                emit(-1, -1);                                    // a record without ops
+            }
             if (rec_start >= cq1) break;                         // the next record starts in a later chunk
         }
+        return true;
+    };
+    // ---- exact chunk: wave scans per record piece (scan_piece)
+    auto exact = [&](const cquad_t quad, const int c) {
+        const int cq0 = c * WAVE, cq1 = cq0 + WAVE;
+        sync_at(c);
+        if (rec_start <= cq0 && rec_end > cq1) {                 // inside one record
+            scan_piece(quad, lane, st, gaps_on, min_gap, half_gap, r, cq0 - rec_start, p0, gaps, gap_count, gap_cap);
+        } else {
+            const int lq = cq0 + lane;
+            while (r < rb) {                                     // once per record present in this chunk
+                const int a = rec_start > cq0 ? rec_start : cq0, b = rec_end < cq1 ? rec_end : cq1;
+                if (b > a) {
+                    cquad_t piece = pad;
+                    if (lq >= a && lq < b) piece = quad;
+                    scan_piece(piece, lane, st, gaps_on, min_gap, half_gap, r, cq0 - rec_start, p0, gaps, gap_count, gap_cap);
+                }
+                if (rec_end > cq1) break;                        // the record continues in the next chunk
+                finish_record();
+                if (rec_start >= cq1) break;                     // the next record starts in a later chunk
+            }
+        }
+        have_first = st.carry_end > 0;
+    };
+
+    // ---- static ring of RING register quads, loop unrolled by RING so that no quad is ever moved: while chunk c is processed
+    // the loads of c + 1 .. c + RING - 1 are in flight (the compiler's counted s_waitcnt vmcnt retires them in order).  Only the
+    // fast chunk code is replicated; a chunk that needs the exact path leaves the pipeline (the loads in flight are dropped),
+    // is handled by the one copy of the exact code below, and the pipeline restarts behind it — rare by construction.
+    int c = 0;
+    const int last_chunk = n_chunks - 1;
+    cquad_t q[RING];
+    auto issue = [&](cquad_t &dst, int cc) {                     // every ring load is issued unconditionally (chunk index clamped to
+        const int k = cc < last_chunk ? cc : last_chunk;         // the group's last chunk): the number in flight is the same on every
+        ring_load(dst, wave_src + (long long)k * (WAVE * 16), lane_offset(k));       // path, and no register is ever copied while its load is in flight
+    };
+    auto drain = [&]() {
+#pragma unroll
+        for (int k = 0; k < RING; ++k) ring_wait<0>(q[k]);
+    };
+    while (c < n_chunks) {
+#pragma unroll
+        for (int k = 0; k < RING - 1; ++k) issue(q[k], c + k);
+        for (;;) {
+#pragma unroll
+            for (int k = 0; k < RING; ++k) {
+                issue(q[(k + RING - 1) % RING], c + k + RING - 1);
+                ring_wait<RING - 1>(q[k]);
+                if (c + k >= n_chunks) { c = n_chunks; goto leave; }
+                if (!fast(q[k], c + k)) { c += k; goto leave; }
+            }
+            c += RING;
+        }
+    leave:
+        drain();                                                 // loads still in flight are dropped
+        if (c >= n_chunks) break;
+        do {                                                     // chunk c, and the chunks a flagged last lane drags along
+            exact(load(c), c);
+            ++c;
+        } while (c < n_chunks && st.tail_flagged);
     }
     while (r < rb) finish_record();                              // records without any op at the end of the range
     if (parked) flush();
+    g = g_next;
+    g_next = dyn_base + (int)__builtin_amdgcn_readfirstlane(ticket);
+    }
 }
 
-extern "C" const char *coral_scan_kernel_name(void) { return "k_cigar_scan_v3<8>"; }
+extern "C" const char *coral_scan_kernel_name(void) { return "k_cigar_scan_v4<6>"; }
 
 static int check_records(const coral_records_t *rec) {
     if (!rec) return set_err(CORAL_ERR_ARG, "records: null");
@@ -348,18 +509,19 @@ static int check_records(const coral_records_t *rec) {
     return CORAL_OK;
 }
 
-// workgroups of the scan: as many as are resident at once (LDS-bound: 36 KiB per workgroup -> 4 per CU), never more waves than records
+// workgroups of the scan: as many as are resident at once (register-bound), never more waves than records.
+// CORAL_SCAN_RING (4 / 6 / 8 / 12), CORAL_SCAN_GROUP (1 .. 64) and CORAL_SCAN_WG_PER_CU: tuning overrides (tools/scan_sweep.sh).
+#define SCAN_RING_DEFAULT 6
+static int g_ring = 0, g_wg_per_cu = 0, g_group = 24;
+template <int RING>
 static int scan_grid(long long n_rec) {
-    static int resident = 0;
-    if (resident == 0) {
-        int per_cu = 0, dev = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cigar_scan_v3<8>, SCAN_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-            cus = 256;
-        resident = per_cu * cus;
-    }
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cigar_scan_v4<RING>, SCAN_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (g_wg_per_cu > 0 && g_wg_per_cu < per_cu) per_cu = g_wg_per_cu;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+        cus = 256;
     long long blocks = (n_rec + (SCAN_BLOCK / WAVE) - 1) / (SCAN_BLOCK / WAVE);
-    if (blocks > resident) blocks = resident;
+    if (blocks > (long long)per_cu * cus) blocks = (long long)per_cu * cus;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
@@ -371,9 +533,20 @@ extern "C" int coral_cigar_scan(const coral_records_t *rec, int32_t min_gap, int
     if (rec->n_rec == 0) return CORAL_OK;
     if (!summary || !gap_count || (gap_cap && !gaps)) return set_err(CORAL_ERR_ARG, "cigar_scan: null output");
     if ((((uintptr_t)gaps) & 15u) || (((uintptr_t)summary) & 15u)) return set_err(CORAL_ERR_ARG, "cigar_scan: summary and gaps must be 16-byte aligned");
-    hipLaunchKernelGGL(k_cigar_scan_v3<8>, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream, (long long)rec->n_rec,
-                       rec->pos, rec->flagmq, rec->cigar_off, rec->cigar, (int)min_gap, (int)min_mapq, reinterpret_cast<int4 *>(summary),
-                       gaps, gap_count, gap_cap);
+    if (g_ring == 0) {
+        const char *a = getenv("CORAL_SCAN_RING"), *b = getenv("CORAL_SCAN_WG_PER_CU"), *c = getenv("CORAL_SCAN_GROUP");
+        g_ring = a ? atoi(a) : SCAN_RING_DEFAULT;
+        g_wg_per_cu = b ? atoi(b) : 0;
+        if (c && atoi(c) >= 1 && atoi(c) <= 64) g_group = atoi(c);
+    }
+#define LAUNCH_V4(R)                                                                                                              \
+    hipLaunchKernelGGL(k_cigar_scan_v4<R>, dim3(scan_grid<R>(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,              \
+                       (long long)rec->n_rec, rec->pos, rec->flagmq, rec->cigar_off, rec->cigar, (int)min_gap, (int)min_mapq,     \
+                       reinterpret_cast<int4 *>(summary), gaps, gap_count, gap_cap, g_group)
+    if (g_ring == 4) LAUNCH_V4(4);
+    else if (g_ring == 8) LAUNCH_V4(8);
+    else if (g_ring == 12) LAUNCH_V4(12);
+    else LAUNCH_V4(6);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_err(e, "cigar_scan launch");
     return CORAL_OK;
@@ -519,6 +692,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_seg_walk(
     }
 }
 
+static int walk_grid(long long n_rec) {          // one wave per straddling record, up to 32 waves per CU
+    long long blocks = (n_rec + (SCAN_BLOCK / WAVE) - 1) / (SCAN_BLOCK / WAVE);
+    if (blocks > 2048) blocks = 2048;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
 extern "C" int coral_segment_coverage(const coral_records_t *rec, const int32_t *summary, int32_t n_seg, const int32_t *seg_tid, const int32_t *seg_start,
                                       const int32_t *seg_end, unsigned long long *n_reads,
                                       unsigned long long *n_bases, uint32_t *strad, uint32_t *strad_count,
@@ -537,7 +716,7 @@ extern "C" int coral_segment_coverage(const coral_records_t *rec, const int32_t 
                        seg_end, n_reads, n_bases, strad, strad_count);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_err(e, "seg_classify launch");
-    hipLaunchKernelGGL(k_seg_walk, dim3(scan_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, s, strad, strad_count, rec->tid,
+    hipLaunchKernelGGL(k_seg_walk, dim3(walk_grid(rec->n_rec)), dim3(SCAN_BLOCK), 0, s, strad, strad_count, rec->tid,
                        rec->pos, rec->end, rec->n_cigar, rec->cigar_off, rec->cigar, (int)n_seg, seg_tid, seg_start,
                        seg_end, n_bases);
     e = hipGetLastError();

@@ -53,7 +53,7 @@ def _scan_local(dr, min_gap: int, min_mapq: int, gap_cap: int):
 
     def launch(cap):
         gaps = torch.empty((cap, 4), dtype=torch.int32, device=dev)
-        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(2, dtype=torch.int32, device=dev)      # [0] gap rows found, [1] the kernel's work cursor
         prof = PROFILE.get("scan_ms")
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -70,7 +70,7 @@ def _scan_local(dr, min_gap: int, min_mapq: int, gap_cap: int):
     def rows():
         while True:
             (gaps, cnt), cap = state
-            k = int(cnt.item()) & 0xFFFFFFFF
+            k = int(cnt[0].item()) & 0xFFFFFFFF
             if k <= cap:
                 break
             cap = 1 << int(np.ceil(np.log2(k + 1)))          # more gap rows than slots: run again with room for all of them

@@ -68,11 +68,12 @@ const char *coral_last_error(void);
  *                                                (blocks[0][0], blocks[-1][1] at :760)
  * and one row (record, op index of the next block, prev block end, next block start) is appended to
  * `gaps` for every pair of consecutive blocks further apart than `min_gap` in a record with
- * mapq >= min_mapq (:754, :757-758).  *gap_count is a device counter the caller zeroes beforehand;
- * rows beyond gap_cap are dropped (the counter still counts them).  summary and gaps must be 16-byte aligned.
+ * mapq >= min_mapq (:754, :757-758).  `counters` are TWO device words the caller zeroes beforehand: [0] counts the
+ * gap rows (rows beyond gap_cap are dropped, the counter still counts them), [1] is the kernel's work cursor.
+ * summary and gaps must be 16-byte aligned.
  * ------------------------------------------------------------------------------------------------ */
 int coral_cigar_scan(const coral_records_t *rec, int32_t min_gap, int32_t min_mapq, int32_t *summary /* [n_rec][4] */,
-                     int32_t *gaps /* [gap_cap][4] */, uint32_t *gap_count, uint32_t gap_cap, void *stream);
+                     int32_t *gaps /* [gap_cap][4] */, uint32_t *counters /* [2] */, uint32_t gap_cap, void *stream);
 /* Name of the kernel behind coral_cigar_scan as rocprofv3 prints it (reported next to the roofline figures). */
 const char *coral_scan_kernel_name(void);
 

@@ -79,7 +79,7 @@ def case(request):
 
 
 def test_cigar_scan(case):
-    """coral_cigar_scan (flat balanced stream through an LDS ring, record boundaries handled per piece) against the oracle's
+    """coral_cigar_scan (record groups from a work cursor, register ring, record boundaries as lane masks) against the oracle's
     per-record blocks: sums, first / last block, every large gap in the reference's order."""
     from coral_amd import kernels
     name, rec, host, dr = case
