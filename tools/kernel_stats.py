@@ -3,8 +3,9 @@ import csv, glob, sys
 d, out_md, out_csv, cmd = sys.argv[1:5]
 f = glob.glob(d + "/**/*_kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
-ours = [r for r in rows if any(t in r["Name"] for t in ("k_cigar_scan", "k_seg_", "k_point_cover", "k_bp_candidates", "k_group_process",
-                                                       "k_exclusive_scan", "k_sa_", "k_mark", "k_gather", "k_scatter"))]
+ours = [r for r in rows if any(t in r["Name"] for t in ("k_cigar_scan", "k_seg_", "k_point_cover", "k_bp_pairs", "k_group_", "k_hash_", "k_count_valid",
+                                                       "k_first_primary", "k_heads", "k_iota", "k_order_counts", "k_read_length", "k_row_keys",
+                                                       "k_scatter", "k_all"))]
 total = sum(float(r["TotalDurationNs"]) for r in rows) / 1e6
 with open(out_csv, "w") as fp:
     w = csv.DictWriter(fp, fieldnames=list(rows[0].keys()))
@@ -12,7 +13,7 @@ with open(out_csv, "w") as fp:
     for r in ours:
         w.writerow(r)
 with open(out_md, "w") as fp:
-    fp.write("# rocprofv3 --kernel-trace --stats (round 1)\n\nCommand: `%s`\n" % cmd)
+    fp.write("# rocprofv3 --kernel-trace --stats (round 2)\n\nCommand: `%s`\n" % cmd)
     fp.write("(config 3: 2,000,000 reads x 20 kb, 2,163,774 records, 3.99e9 CIGAR ops = 16.04 GB algorithmic bytes per scan launch).\n\n")
     fp.write("The run also contains the synthetic-data generator and hipcub/rocprim sorts: %d kernel rows, %.1f ms in total.\n" % (len(rows), total))
     fp.write("Kernels of libcoral_hip.so:\n\n| kernel | calls | total ms | avg ms | min ms | max ms |\n|---|---|---|---|---|---|\n")
