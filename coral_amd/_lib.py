@@ -39,7 +39,7 @@ def lib():
     L.coral_cigar_scan.argtypes = [R, C.c_int32, C.c_int32, P, P, P, C.c_uint32, P]
     L.coral_scan_kernel_name.restype = C.c_char_p
     L.coral_segment_coverage.argtypes = [R, P, C.c_int32, P, P, P, P, P, P, P, P]
-    L.coral_point_cover.argtypes = [R, C.c_int32, P, P, P, P, C.c_uint32, P]
+    L.coral_point_cover.argtypes = [R, C.c_int32, P, P, C.c_int32, P, P, C.c_uint32, P]
     L.coral_read_counter.argtypes = [P, C.POINTER(C.c_uint32), P]
     L.coral_first_seen_rows.argtypes = [C.c_int64, C.c_int32, P, P]
     L.coral_first_seen_rows.restype = C.c_int

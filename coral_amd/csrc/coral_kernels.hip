@@ -556,7 +556,7 @@ extern "C" int coral_cigar_scan(const coral_records_t *rec, int32_t min_gap, int
 // K2  segment coverage
 //   phase A (thread per record): classify against the sorted disjoint segment table; records fully
 //            inside one segment add mbases; boundary-straddling records are compacted into a list;
-//   phase B (wave per straddler): walk the CIGAR once per overlapped segment.
+//   phase B (wave per straddler): walk the CIGAR once for up to four overlapped segments.
 // ---------------------------------------------------------------------------------------------
 #define COV_BLOCK 256
 #define COV_LDS_SEGS 2048
@@ -638,56 +638,130 @@ __global__ __launch_bounds__(COV_BLOCK) void k_seg_classify(
     }
 }
 
+#define WALK_SEGS 4          // segments evaluated per walk of a record's CIGAR (a record rarely straddles more than two)
+
+// first j with (seg_tid[j], seg_end[j]) > (tid, p) — the whole wave probes 64 table entries per step (two steps for 4096 segments
+// instead of twelve dependent loads)
+__device__ __forceinline__ int first_seg_ending_after_wave(const int32_t *__restrict__ seg_tid, const int32_t *__restrict__ seg_end,
+                                                           int n_seg, int tid, int p, int lane) {
+    int lo = 0, hi = n_seg;                       // answer in [lo, hi]
+    while (hi - lo > 64) {
+        const int idx = lo + (int)(((long long)(hi - lo) * (lane + 1)) / 65);       // lo < idx_0 < ... < idx_63 < hi
+        const int t = seg_tid[idx];
+        const unsigned long long m = __ballot((t > tid) || (t == tid && seg_end[idx] > p));
+        const int f = m == 0ull ? 64 : (int)__builtin_ctzll(m);
+        const int lo_new = f == 0 ? lo : lo + (int)(((long long)(hi - lo) * f) / 65) + 1;
+        const int hi_new = f == 64 ? hi : lo + (int)(((long long)(hi - lo) * (f + 1)) / 65);
+        lo = lo_new;
+        hi = hi_new;
+    }
+    const int idx = lo + lane;
+    const int ii = idx < n_seg ? idx : n_seg - 1;
+    const int t = seg_tid[ii];
+    const unsigned long long m = __ballot(idx < hi && ((t > tid) || (t == tid && seg_end[ii] > p)));
+    return m == 0ull ? hi : lo + (int)__builtin_ctzll(m);
+}
+
+// phase B: one wave per straddling record; the record's CIGAR is walked once for up to WALK_SEGS overlapped segments, the next
+// chunk and the next straddler's fields are requested while the current ones are evaluated.  The thousands of records that
+// straddle the same segment boundary at amplicon depth all add to the same two counters: each workgroup takes a CONTIGUOUS
+// piece of the straddler list (neighbours in file order), sums in LDS and issues one global atomic per touched segment (same-
+// address global atomics run at ~80 M / s: one per straddler made this kernel 0.45 - 0.86 ms per call at config 3).
 __global__ __launch_bounds__(SCAN_BLOCK) void k_seg_walk(
     const uint32_t *__restrict__ strad, const uint32_t *__restrict__ strad_count,
     const int32_t *__restrict__ tid, const int32_t *__restrict__ pos, const int32_t *__restrict__ end,
     const int32_t *__restrict__ n_cigar, const int64_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar,
     int n_seg, const int32_t *__restrict__ seg_tid, const int32_t *__restrict__ seg_start,
     const int32_t *__restrict__ seg_end, unsigned long long *__restrict__ n_bases) {
-    const int lane = threadIdx.x & 63;
-    const long long wave = (long long)blockIdx.x * (SCAN_BLOCK / WAVE) + (threadIdx.x >> 6);
-    const long long nwaves = (long long)gridDim.x * (SCAN_BLOCK / WAVE);
+    __shared__ unsigned long long bins[COV_LDS_SEGS];
+    const bool use_lds = n_seg <= COV_LDS_SEGS;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < n_seg; i += SCAN_BLOCK) bins[i] = 0ull;
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const long long n_strad = *strad_count;
     const cquad_t pad = {OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD, OP_PAD_QUAD};
-    for (long long w = wave; w < n_strad; w += nwaves) {
-        const long long r = strad[w];
-        const int t = tid[r], p0 = pos[r], e0 = end[r];
-        const int nq = (n_cigar[r] + 3) >> 2;
-        const cquad_t *__restrict__ q = reinterpret_cast<const cquad_t *>(cigar + cigar_off[r]);
-        int j = first_seg_ending_after(seg_tid, seg_end, n_seg, t, p0);
-        for (; j < n_seg && seg_tid[j] == t && seg_start[j] < e0; ++j) {
-            const int s = seg_start[j] - p0, e = seg_end[j] - p0;    // segment in record-relative coordinates
-            long long acc = 0;
+    const long long per_block = (n_strad + gridDim.x - 1) / gridDim.x;
+    const long long w_begin = (long long)blockIdx.x * per_block;
+    const long long w_end = w_begin + per_block < n_strad ? w_begin + per_block : n_strad;
+    const int nwaves = SCAN_BLOCK / WAVE;                        // stride inside the block's piece
+    const long long wave = w_begin + wib;
+    if (wave < w_end) {
+    long long r_next = strad[wave];
+    int t_next = tid[r_next], p_next = pos[r_next], e_next = end[r_next], nc_next = n_cigar[r_next];
+    long long off_next = cigar_off[r_next];
+    for (long long w = wave; w < w_end; w += nwaves) {
+        const int t = t_next, p0 = p_next, e0 = e_next;
+        const int nq = (nc_next + 3) >> 2;
+        const cquad_t *__restrict__ q = reinterpret_cast<const cquad_t *>(cigar + off_next);
+        if (w + nwaves < w_end) {                                // (wave-uniform) the next straddler of this wave
+            r_next = strad[w + nwaves];
+            t_next = tid[r_next]; p_next = pos[r_next]; e_next = end[r_next]; nc_next = n_cigar[r_next];
+            off_next = cigar_off[r_next];
+        }
+        cquad_t cur = lane < nq ? q[lane] : pad;                 // chunk 0 is on its way while the segments are located
+        int j = first_seg_ending_after_wave(seg_tid, seg_end, n_seg, t, p0, lane);
+        while (j < n_seg && seg_tid[j] == t && seg_start[j] < e0) {
+            // up to WALK_SEGS overlapped segments per walk, in record-relative coordinates (an unused slot is empty: s = e = 0)
+            int s[WALK_SEGS], e[WALK_SEGS], e_max = 0, n_here = 0;
+#pragma unroll
+            for (int k = 0; k < WALK_SEGS; ++k) {
+                const bool on = j + k < n_seg && seg_tid[j + k] == t && seg_start[j + k] < e0;
+                s[k] = on ? seg_start[j + k] - p0 : 0;
+                e[k] = on ? seg_end[j + k] - p0 : 0;
+                e_max = on && e[k] > e_max ? e[k] : e_max;
+                n_here += on ? 1 : 0;
+            }
+            int acc[WALK_SEGS] = {0, 0, 0, 0};       // per lane: < 2^31 (a record's aligned bases)
             int carry_ref = 0;
-            for (int c = 0; c < nq && carry_ref < e; c += WAVE) {
-                cquad_t cur = pad;
-                if (c + lane < nq) cur = q[c + lane];
-                const uint32_t v[4] = {cur.x, cur.y, cur.z, cur.w};
-                int len[4], adv[4];
-                bool aln[4];
+            for (int c = 0; c < nq && carry_ref < e_max; c += WAVE) {
+                const cquad_t nxt = c + WAVE + lane < nq ? q[c + WAVE + lane] : pad;       // in flight while `cur` is evaluated
+                int len[4], adv[4], fal[4];
                 int tot = 0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const uint32_t op = v[k] & 15u;
-                    len[k] = (int)(v[k] >> 4);
-                    adv[k] = ((MASK_REF >> op) & 1u) ? len[k] : 0;
-                    aln[k] = (MASK_ALN >> op) & 1u;
+                    const uint32_t v = cur[k];
+                    len[k] = (int)(v >> 4);
+                    adv[k] = len[k] & __builtin_amdgcn_sbfe((int)(MASK_REF * 0x10001u), v, 1u);
+                    fal[k] = __builtin_amdgcn_sbfe((int)(MASK_ALN * 0x10001u), v, 1u);
                     tot += adv[k];
                 }
-                const int incl = wave_incl_scan_add(tot, lane);
+                const int incl = wave_incl_scan_add_dpp(tot);
                 int ref = carry_ref + incl - tot;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (aln[k]) {
-                        const int ov = min(ref + len[k], e) - max(ref, s);
-                        if (ov > 0) acc += ov;
+                    const int a0 = ref, a1 = ref + (len[k] & fal[k]);            // the aligned block of this op (empty if not aligned)
+#pragma unroll
+                    for (int g = 0; g < WALK_SEGS; ++g) {
+                        const int ov = min(a1, e[g]) - max(a0, s[g]);
+                        acc[g] += ov > 0 ? ov : 0;
                     }
                     ref += adv[k];
                 }
-                carry_ref += __shfl(incl, 63);
+                carry_ref += __builtin_amdgcn_readlane(incl, 63);
+                cur = nxt;
             }
-            acc = wave_reduce_add64(acc);
-            if (lane == 0 && acc) atomicAdd(&n_bases[j], (unsigned long long)acc);
+#pragma unroll
+            for (int g = 0; g < WALK_SEGS; ++g) {
+                if (g < n_here) {                                                // (wave-uniform)
+                    const long long sum = wave_reduce_add64((long long)acc[g]);
+                    if (lane == 0 && sum) {
+                        if (use_lds) atomicAdd(&bins[j + g], (unsigned long long)sum);
+                        else atomicAdd(&n_bases[j + g], (unsigned long long)sum);
+                    }
+                }
+            }
+            j += n_here;
+            if (j < n_seg && seg_tid[j] == t && seg_start[j] < e0) cur = lane < nq ? q[lane] : pad;     // another walk: from the top
+        }
+    }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_seg; i += SCAN_BLOCK) {
+            const unsigned long long b = bins[i];
+            if (b) atomicAdd(&n_bases[i], b);
         }
     }
 }
@@ -725,63 +799,90 @@ extern "C" int coral_segment_coverage(const coral_records_t *rec, const int32_t 
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3  point cover — thread per record, sorted query points
+// K3  point cover — one workgroup per query point.  Records are in (tid, pos) order, so the records covering (t, p) lie in
+// the index window  [first record at (t, p - max_span + 1),  first record behind (t, p)):  two cooperative 64-ary searches, then
+// a strided look at `end` inside the window only (round 1 searched the point table once per RECORD: 2 M searches per call).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long rec_key(const int32_t *__restrict__ tid, const int32_t *__restrict__ pos, long long r) {
+    return ((unsigned long long)(uint32_t)tid[r] << 32) | (unsigned long long)(uint32_t)pos[r];    // unmapped (tid -1) sorts last, as in the file
+}
+
+// first record r in [0, n_rec] with (tid, pos) >= key — 64 probes per step, all lanes of the wave take part
+__device__ __forceinline__ long long first_rec_at_key(const int32_t *__restrict__ tid, const int32_t *__restrict__ pos, long long n_rec,
+                                                      unsigned long long key, int lane) {
+    long long lo = 0, hi = n_rec;                 // answer in [lo, hi]
+    while (hi - lo > 64) {
+        const long long idx = lo + ((hi - lo) * (long long)(lane + 1)) / 65;        // lo < idx_0 < ... < idx_63 < hi
+        const unsigned long long m = __ballot(rec_key(tid, pos, idx) >= key);       // 0..0 1..1 from some lane on
+        const int f = m == 0ull ? 64 : (int)__builtin_ctzll(m);
+        const long long lo_new = f == 0 ? lo : (lo + ((hi - lo) * (long long)f) / 65) + 1;
+        const long long hi_new = f == 64 ? hi : lo + ((hi - lo) * (long long)(f + 1)) / 65;
+        lo = lo_new;
+        hi = hi_new;
+    }
+    const long long idx = lo + lane;
+    const bool ge = idx < hi && rec_key(tid, pos, idx < n_rec ? idx : n_rec - 1) >= key;
+    const unsigned long long m = __ballot(ge);
+    return m == 0ull ? hi : lo + (long long)__builtin_ctzll(m);
+}
+
+#define POINT_SLICES 32
 __global__ __launch_bounds__(COV_BLOCK) void k_point_cover(
     long long n_rec, const int32_t *__restrict__ tid, const int32_t *__restrict__ pos,
     const int32_t *__restrict__ end, int n_pts, const int32_t *__restrict__ pt_tid,
-    const int32_t *__restrict__ pt_pos, unsigned long long *__restrict__ pairs,
+    const int32_t *__restrict__ pt_pos, int max_span, unsigned long long *__restrict__ pairs,
     uint32_t *__restrict__ pair_count, uint32_t pair_cap) {
-    const int lane = threadIdx.x & 63;
-    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const long long stride = (long long)gridDim.x * COV_BLOCK;
-    const long long n_round = (n_rec + stride - 1) / stride * stride;      // whole waves stay in the loop (ballots)
-    for (long long r = (long long)blockIdx.x * COV_BLOCK + threadIdx.x; r < n_round; r += stride) {
-        int j = n_pts, t = -1, e = 0;
-        if (r < n_rec) {
-            t = tid[r];
-            const int p = pos[r];
-            e = end[r];
-            if (t >= 0) {        // first point with (pt_tid, pt_pos) >= (t, p)
-                int lo = 0, hi = n_pts;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    const int pt = pt_tid[mid];
-                    const bool ge = (pt > t) || (pt == t && pt_pos[mid] >= p);
-                    if (ge) hi = mid; else lo = mid + 1;
-                }
-                j = lo;
-            }
+    __shared__ uint32_t wave_hits[COV_BLOCK / WAVE];
+    __shared__ uint32_t job_base;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    // POINT_SLICES workgroups share the window of one point (thousands of records at amplicon depth), interleaved by rounds.
+    // Two passes over the slice: count, reserve the output range with ONE atomic per workgroup (a shared cursor serves only
+    // ~80 M requests / s: with one atomic per wave and round the launch took 0.45 ms whatever else it did), then write.
+    const long long stride = (long long)POINT_SLICES * COV_BLOCK;
+    for (long long job = blockIdx.x; job < (long long)n_pts * POINT_SLICES; job += gridDim.x) {
+        const int j = (int)(job / POINT_SLICES), slice = (int)(job % POINT_SLICES);
+        const int t = pt_tid[j], p = pt_pos[j];
+        if (t < 0 || p < 0) continue;                            // (block-uniform) nothing covers a negative coordinate
+        const long long first_pos = max_span > 0 && p - max_span + 1 > 0 ? p - max_span + 1 : 0;
+        // every wave runs both searches (same probes: all but the first hit the cache)
+        const long long lo = first_rec_at_key(tid, pos, n_rec, ((unsigned long long)(uint32_t)t << 32) | (unsigned long long)first_pos, lane);
+        const long long hi = first_rec_at_key(tid, pos, n_rec, ((unsigned long long)(uint32_t)t << 32) | ((unsigned long long)(uint32_t)p + 1ull), lane);
+        uint32_t mine = 0;
+        for (long long k = (long long)slice * COV_BLOCK + threadIdx.x; lo + k < hi; k += stride) mine += end[lo + k] > p ? 1u : 0u;
+        const uint32_t incl = (uint32_t)wave_incl_scan_add_dpp((int)mine);
+        __syncthreads();                                         // the previous job's readers of the shared words are done
+        if (lane == 63) wave_hits[wib] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+            for (int k = 0; k < COV_BLOCK / WAVE; ++k) total += wave_hits[k];
+            job_base = total ? atomicAdd(pair_count, total) : 0u;
         }
-        // emit one covered point per round: ballot + popcount gives each lane its slot, one atomic per wave
-        for (;;) {
-            const bool hit = j < n_pts && pt_tid[j] == t && pt_pos[j] < e;
-            const unsigned long long m = __ballot(hit);
-            if (m == 0ull) break;
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(pair_count, (uint32_t)__popcll(m));
-            base = __shfl(base, 0);
-            if (hit) {
-                const uint32_t slot = base + (uint32_t)__popcll(m & below);
+        __syncthreads();
+        uint32_t slot = job_base + incl - mine;
+        for (int k = 0; k < wib; ++k) slot += wave_hits[k];
+        for (long long k = (long long)slice * COV_BLOCK + threadIdx.x; lo + k < hi; k += stride) {
+            const long long r = lo + k;
+            if (end[r] > p) {                                    // tid == t and pos <= p hold for the whole window
                 if (slot < pair_cap) pairs[slot] = ((unsigned long long)(uint32_t)j << 32) | (unsigned long long)(uint32_t)r;
-                ++j;
+                ++slot;
             }
         }
     }
 }
 
 extern "C" int coral_point_cover(const coral_records_t *rec, int32_t n_pts, const int32_t *pt_tid,
-                                 const int32_t *pt_pos, unsigned long long *pairs, uint32_t *pair_count,
+                                 const int32_t *pt_pos, int32_t max_span, unsigned long long *pairs, uint32_t *pair_count,
                                  uint32_t pair_cap, void *stream) {
     int rc = check_records(rec);
     if (rc) return rc;
     if (n_pts < 0) return set_err(CORAL_ERR_ARG, "point_cover: n_pts < 0");
     if (n_pts == 0 || rec->n_rec == 0) return CORAL_OK;
     if (!pt_tid || !pt_pos || !pair_count || (pair_cap && !pairs)) return set_err(CORAL_ERR_ARG, "point_cover: null argument");
-    long long blocks = (rec->n_rec + COV_BLOCK - 1) / COV_BLOCK;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_point_cover, dim3((int)blocks), dim3(COV_BLOCK), 0, (hipStream_t)stream, (long long)rec->n_rec,
-                       rec->tid, rec->pos, rec->end, (int)n_pts, pt_tid, pt_pos, pairs, pair_count, pair_cap);
+    const long long jobs = (long long)n_pts * POINT_SLICES;
+    const int blocks = (int)(jobs < 8192 ? jobs : 8192);
+    hipLaunchKernelGGL(k_point_cover, dim3(blocks), dim3(COV_BLOCK), 0, (hipStream_t)stream, (long long)rec->n_rec,
+                       rec->tid, rec->pos, rec->end, (int)n_pts, pt_tid, pt_pos, (int)max_span, pairs, pair_count, pair_cap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_err(e, "point_cover launch");
     return CORAL_OK;

@@ -182,7 +182,7 @@ def _points_local(dr, uniq: np.ndarray, pair_cap: int) -> torch.Tensor:
     while True:
         pairs = torch.empty(pair_cap, dtype=torch.int64, device=dev)
         cnt = torch.zeros(1, dtype=torch.int32, device=dev)
-        _lib.check(L.coral_point_cover(C.byref(rs), len(uniq), t.data_ptr(), p.data_ptr(), pairs.data_ptr(),
+        _lib.check(L.coral_point_cover(C.byref(rs), len(uniq), t.data_ptr(), p.data_ptr(), dr.max_span, pairs.data_ptr(),
                                        cnt.data_ptr(), pair_cap, dr.stream()), "coral_point_cover")
         k = int(cnt.item()) & 0xFFFFFFFF
         if k <= pair_cap:

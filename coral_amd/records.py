@@ -122,6 +122,8 @@ class DeviceRecords:
         self.tid = i32(rec.tid)
         self.pos = i32(rec.pos)
         self.end = i32(rec.end)
+        # the longest reference span of a local alignment: bounds the window coral_point_cover looks at per query point
+        self.max_span = int((self.end - self.pos).max()) if self.n else 0
         flagmq = (rec.flag.to(torch.int64) & 0xFFFF) | ((rec.mapq.to(torch.int64) & 0xFF) << 16) | \
                  ((rec.has_seq.to(torch.int64) & 1) << 24)
         self.flagmq = i32(flagmq)

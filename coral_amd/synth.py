@@ -891,6 +891,20 @@ def _hsr_edge_alignments(cfg: SynthConfig) -> List[dict]:
     return sorted(out, key=lambda r: (r["tid"], r["pos"]))
 
 
+def with_decoy_contigs(rec: Records, n_decoys: int = 100) -> Records:
+    """The same alignments under a header that lists `n_decoys` short contigs BEFORE chr1 (as references with decoys / alt
+    contigs sorted first do): every target id — records and SA rows — moves up by n_decoys, names and coordinates stay."""
+    kw = dict(rec.__dict__)
+    kw["tid"] = torch.where(rec.tid >= 0, rec.tid + n_decoys, rec.tid)
+    sa = rec.sa.clone()
+    if sa.numel():
+        sa[:, 0] += n_decoys
+    kw["sa"] = sa
+    kw["header_chroms"] = ["decoy%03d" % k for k in range(n_decoys)] + list(rec.header_chroms)
+    kw["header_lens"] = [5000 + k for k in range(n_decoys)] + list(rec.header_lens)
+    return Records(**kw)
+
+
 def dataset(name: str, device="cpu") -> Tuple[SynthConfig, Records]:
     """Named data set = configuration + records ('tiny_edge' = 'tiny' plus hand-written corner-case records)."""
     if name == "tiny_edge":

@@ -103,9 +103,12 @@ int coral_segment_coverage(const coral_records_t *rec, const int32_t *summary /*
  * (/root/reference/src/infer_breakpoint_graph.py:1043-1046): for P points sorted by (tid, pos) appends
  * the packed pair (point index << 32 | record ordinal) for every record with pos <= p < end.
  * *pair_count is a zeroed device counter; pairs beyond pair_cap are dropped (still counted).
+ * max_span: an upper bound of end - pos over the records (the longest reference span of an alignment), which confines the
+ * search to the records starting within max_span in front of a point; <= 0 = unknown (the window starts at the contig's
+ * first record).  Relies on the (tid, pos) order of the record layout.
  * ------------------------------------------------------------------------------------------------ */
 int coral_point_cover(const coral_records_t *rec, int32_t n_pts, const int32_t *pt_tid,
-                      const int32_t *pt_pos, unsigned long long *pairs, uint32_t *pair_count,
+                      const int32_t *pt_pos, int32_t max_span, unsigned long long *pairs, uint32_t *pair_count,
                       uint32_t pair_cap, void *stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -70,6 +70,32 @@ def test_gpu_matches_oracle_subsample(config, n_reads, tmp_path):
         assert os.path.exists(str(tmp_path / ("gpu_amplicon%d_graph.txt" % (k + 1))))
 
 
+def test_decoy_contigs_before_chr1(tmp_path):
+    """A BAM header with 100 decoy contigs in front of chr1 (target ids 100 .. 124 instead of 0 .. 24): the product's graph
+    files equal the ones it writes for the plain header byte for byte, and both equal the oracle's on the shifted records."""
+    from coral_amd import infer_breakpoint_graph as ibg
+    from coral_amd.records import DeviceRecords
+    from oracle import coral_oracle as O
+    from oracle.hostrecords import HostRecords
+    cfg, rec = synth.dataset("cfg3_12k", "cpu")
+    shifted = synth.with_decoy_contigs(rec, 100)
+    assert int(shifted.tid.max()) >= 100 and shifted.header_chroms[100] == "chr1"
+    cn = str(tmp_path / "cn.bed"); seeds = str(tmp_path / "seeds.bed")
+    synth.write_cn_bed(cfg, cn); synth.write_seed_bed(cfg, seeds)
+    a = ibg.build_graph_from_records(DeviceRecords(rec, "cuda:0"), seeds, cn, str(tmp_path / "plain"))
+    b = ibg.build_graph_from_records(DeviceRecords(shifted, "cuda:0"), seeds, cn, str(tmp_path / "decoy"))
+    ob, _ = O.reconstruct_graph(HostRecords(shifted), seeds, cn)
+    assert len(a.lr_graph) == len(b.lr_graph) == len(ob.lr_graph) >= 1
+    for k, (g, og) in enumerate(zip(b.lr_graph, ob.lr_graph)):
+        assert open(str(tmp_path / ("plain_amplicon%d_graph.txt" % (k + 1)))).read() == \
+            open(str(tmp_path / ("decoy_amplicon%d_graph.txt" % (k + 1)))).read()
+        assert [e[:8] for e in g.sequence_edges] == [e[:8] for e in og.sequence_edges]
+        assert [e[8] for e in g.concordant_edges] == [e[8] for e in og.concordant_edges]
+        assert sorted(map(str, (e[:6] + [e[9]] for e in g.discordant_edges))) == \
+            sorted(map(str, (e[:6] + [e[9]] for e in og.discordant_edges)))
+        assert len(g.discordant_edges) > 5
+
+
 def test_properties_at_scale():
     """Size-independent checks on 60k reads x 20 kb (≈ 1.2e8 CIGAR ops) generated on the GPU."""
     import torch

@@ -63,3 +63,23 @@ def test_result_holds_no_reference_cycles(monkeypatch, tmp_path):
         assert probe() is None and graphs() is None, "the result is kept alive by a reference cycle"
     finally:
         gc.enable()
+
+
+def test_decoy_contigs_before_chr1(monkeypatch, tmp_path):
+    """Target ids 100 .. 124 (a header with 100 decoy contigs in front of chr1): the host logic writes the same graph files as
+    for the plain header, byte for byte (the group keys, the chromosome ranks and the search tables hold the id, not a 6-bit
+    field of it)."""
+    from coral_amd import infer_breakpoint_graph as ibg, synth
+    from coral_amd.records import DeviceRecords
+    install_cpu_kernel_fakes(monkeypatch)
+    cfg, rec = synth.dataset("small", "cpu")
+    shifted = synth.with_decoy_contigs(rec, 100)
+    cn, seeds = str(tmp_path / "cn.bed"), str(tmp_path / "seeds.bed")
+    synth.write_cn_bed(cfg, cn)
+    synth.write_seed_bed(cfg, seeds)
+    a = ibg.build_graph_from_records(DeviceRecords(rec, "cpu"), seeds, cn, str(tmp_path / "plain"))
+    b = ibg.build_graph_from_records(DeviceRecords(shifted, "cpu"), seeds, cn, str(tmp_path / "decoy"))
+    assert len(a.lr_graph) == len(b.lr_graph) >= 1 and a.new_bp_stats == b.new_bp_stats
+    for k in range(len(a.lr_graph)):
+        ta = open(str(tmp_path / ("plain_amplicon%d_graph.txt" % (k + 1)))).read()
+        assert ta == open(str(tmp_path / ("decoy_amplicon%d_graph.txt" % (k + 1)))).read() and "discordant" in ta
