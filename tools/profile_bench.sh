@@ -6,6 +6,6 @@ rm -rf $O && mkdir -p $O
 CMD="rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 bench.py --steps 5 --warmup 2 --cpu-sample 0 --bam-reads 0"
 timeout -k 10 500 $CMD > gpurun_out/bench_profiled.log 2>&1 || { tail -5 gpurun_out/bench_profiled.log; exit 1; }
 python tools/kernel_stats.py $O gpurun_out/r02_rocprofv3_kernel_stats_bench_cfg3.md gpurun_out/r02_rocprofv3_kernel_stats_bench_cfg3.csv "$CMD" > /dev/null
-tail -1 gpurun_out/bench_profiled.log > gpurun_out/bench_profiled_line.json
+grep '^{"metric"' gpurun_out/bench_profiled.log | tail -1 > gpurun_out/bench_profiled_line.json
 rm -rf $O
 cat gpurun_out/r02_rocprofv3_kernel_stats_bench_cfg3.md
