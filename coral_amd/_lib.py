@@ -99,6 +99,17 @@ def lib():
     L.coral_bam_decode_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.coral_bam_write.argtypes = [C.c_char_p, C.c_int64] + [P] * 9 + [P, P, P, P, P, C.c_int64, P, P, P, C.c_int32, P, P, C.c_uint32,
                                                                         C.c_int32, C.c_int32]
+    L.coral_bamgpu_open.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.coral_bamgpu_start.argtypes = [C.c_void_p, P, C.c_int64]
+    L.coral_bamgpu_next.argtypes = [C.c_void_p, C.POINTER(C.c_int64), P]
+    L.coral_bamgpu_emit.argtypes = [C.c_void_p, P, P, P]
+    L.coral_bamgpu_host.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.coral_bamgpu_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    L.coral_bamgpu_close.argtypes = [C.c_void_p]
+    L.coral_bgzf_inflate.argtypes = [P, P, C.c_int32, P, P, P]
+    for name in ("coral_bamgpu_open", "coral_bamgpu_start", "coral_bamgpu_next", "coral_bamgpu_emit", "coral_bamgpu_host",
+                 "coral_bamgpu_stats", "coral_bamgpu_close", "coral_bgzf_inflate"):
+        getattr(L, name).restype = C.c_int
     for name in ("coral_bam_decode_open", "coral_bam_decode_sizes", "coral_bam_decode_fill", "coral_bam_decode_close",
                  "coral_bam_decode_range", "coral_bam_decode_stats", "coral_bam_write"):
         getattr(L, name).restype = C.c_int

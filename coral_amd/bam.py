@@ -52,36 +52,106 @@ def decode_bam(path: str, n_threads: Optional[int] = None, rank: int = 0, world:
     LAST_DECODE.update(seconds=float(secs.value), compressed_bytes=int(st[0]), uncompressed_bytes=int(st[1]), blocks=int(st[2]),
                        threads=int(n_threads))
     try:
-        sz = (C.c_int64 * 8)()
-        _lib.check(L.coral_bam_decode_sizes(h, sz), "coral_bam_decode_sizes")
-        n, ncig, nsa, nna, nnames, nbytes, nref, rbytes = (int(v) for v in sz)
-        i32 = lambda k: np.empty(max(k, 0), dtype=np.int32)
-        tid, pos, end, flag, mapq, qlen, has_seq, nm, name_id, n_cigar = (i32(n) for _ in range(10))
-        cigar_off = np.empty(n + 1, dtype=np.int64)
-        cigar = np.empty(ncig, dtype=np.uint32)
-        sa_off = np.empty(n + 1, dtype=np.int64)
-        sa = np.empty((nsa, 8), dtype=np.int32)
-        sa_nm = i32(nsa)
-        na_rec = np.empty(nna, dtype=np.int64)
-        na_pos = i32(nna)
-        names_buf = C.create_string_buffer(max(nbytes, 1))
-        ref_buf = C.create_string_buffer(max(rbytes, 1))
-        ref_lens = i32(nref)
-        ptr = lambda a: a.ctypes.data
-        _lib.check(L.coral_bam_decode_fill(h, ptr(tid), ptr(pos), ptr(end), ptr(flag), ptr(mapq), ptr(qlen), ptr(has_seq),
-                                           ptr(nm), ptr(name_id), ptr(n_cigar), ptr(cigar_off), ptr(cigar), ptr(sa_off),
-                                           ptr(sa), ptr(sa_nm), ptr(na_rec), ptr(na_pos), C.addressof(names_buf),
-                                           C.addressof(ref_buf), ptr(ref_lens)), "coral_bam_decode_fill")
+        return _records_from_handle(L, h, None, 0)
     finally:
         L.coral_bam_decode_close(h)
+
+
+def _records_from_handle(L, h, cigar, cigar_words: int) -> Records:
+    """Fill a Records object from a decode handle (coral_bam_decode_sizes / _fill).  ``cigar`` None: the handle holds the op
+    words (CPU pipeline); a tensor: the ops are already on the device (GPU pipeline) and the handle holds everything else."""
+    sz = (C.c_int64 * 8)()
+    _lib.check(L.coral_bam_decode_sizes(h, sz), "coral_bam_decode_sizes")
+    n, ncig, nsa, nna, nnames, nbytes, nref, rbytes = (int(v) for v in sz)
+    i32 = lambda k: np.empty(max(k, 0), dtype=np.int32)
+    tid, pos, end, flag, mapq, qlen, has_seq, nm, name_id, n_cigar = (i32(n) for _ in range(10))
+    cigar_off = np.empty(n + 1, dtype=np.int64)
+    host_cigar = np.empty(ncig, dtype=np.uint32) if cigar is None else None
+    sa_off = np.empty(n + 1, dtype=np.int64)
+    sa = np.empty((nsa, 8), dtype=np.int32)
+    sa_nm = i32(nsa)
+    na_rec = np.empty(nna, dtype=np.int64)
+    na_pos = i32(nna)
+    names_buf = C.create_string_buffer(max(nbytes, 1))
+    ref_buf = C.create_string_buffer(max(rbytes, 1))
+    ref_lens = i32(nref)
+    ptr = lambda a: a.ctypes.data
+    _lib.check(L.coral_bam_decode_fill(h, ptr(tid), ptr(pos), ptr(end), ptr(flag), ptr(mapq), ptr(qlen), ptr(has_seq),
+                                       ptr(nm), ptr(name_id), ptr(n_cigar), ptr(cigar_off), ptr(host_cigar) if host_cigar is not None else None,
+                                       ptr(sa_off), ptr(sa), ptr(sa_nm), ptr(na_rec), ptr(na_pos), C.addressof(names_buf),
+                                       C.addressof(ref_buf), ptr(ref_lens)), "coral_bam_decode_fill")
     names = names_buf.raw[:nbytes].split(b"\0")[:nnames]
     refs = ref_buf.raw[:rbytes].split(b"\0")[:nref]
     t = torch.from_numpy
+    if cigar is None:
+        cigar = t(host_cigar.view(np.int32))
+    else:
+        assert int(cigar_off[-1]) == cigar_words, "device CIGAR words and host offsets disagree"
     return Records(n=n, tid=t(tid), pos=t(pos), end=t(end), flag=t(flag), mapq=t(mapq), qlen=t(qlen), has_seq=t(has_seq),
                    nm=t(nm), name_id=t(name_id), n_cigar=t(n_cigar), cigar_off=t(cigar_off),
-                   cigar=t(cigar.view(np.int32)), sa_off=t(sa_off), sa=t(sa), sa_nm=t(sa_nm), nonacgt_rec=t(na_rec),
+                   cigar=cigar, sa_off=t(sa_off), sa=t(sa), sa_nm=t(sa_nm), nonacgt_rec=t(na_rec),
                    nonacgt_pos=t(na_pos), n_names=nnames, name_gid=None, names=[x.decode() for x in names],
                    header_chroms=[x.decode() for x in refs], header_lens=[int(x) for x in ref_lens])
+
+
+def decode_bam_gpu(path: str, device="cuda:0", n_threads: Optional[int] = None, rank: int = 0, world: int = 1,
+                   batch_bytes: int = 0) -> Records:
+    """The same result as ``decode_bam`` with the inflate and the record parsing on the GPU (csrc/coral_bamgpu.hip): the host
+    only reads the file and uploads COMPRESSED bytes; the CIGAR words of the returned Records are a device tensor (they never
+    exist in host memory), everything else is host-side as before.  ``batch_bytes``: inflated bytes per batch (0 = 1 GiB)."""
+    L = _lib.lib()
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise _lib.CoralHipError("decode_bam_gpu needs a GPU device (the CPU pipeline is decode_bam)")
+    torch.cuda.set_device(dev)
+    if n_threads is None:
+        n_threads = default_threads()
+    h, ws_bytes = C.c_void_p(), C.c_int64(0)
+    rc = L.coral_bamgpu_open(path.encode(), n_threads, rank, world, batch_bytes, C.byref(h), C.byref(ws_bytes))
+    if rc != 0:
+        raise _lib.CoralHipError("coral_bamgpu_open(%s) failed (%d): %s" % (path, rc, L.coral_bam_last_error().decode()))
+    try:
+        ws = torch.empty(int(ws_bytes.value) + 256, dtype=torch.uint8, device=dev)
+        base = (ws.data_ptr() + 255) & ~255
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        fail = lambda what, rc: _lib.CoralHipError("%s(%s) failed (%d): %s" % (what, path, rc, L.coral_bam_last_error().decode()))
+        rc = L.coral_bamgpu_start(h, base, int(ws_bytes.value))
+        if rc != 0:
+            raise fail("coral_bamgpu_start", rc)
+        pieces, total = [], 0
+        out = (C.c_int64 * 4)()
+        while True:
+            rc = L.coral_bamgpu_next(h, out, stream)
+            if rc != 0:
+                raise fail("coral_bamgpu_next", rc)
+            if not out[2]:
+                break
+            words = int(out[1])
+            piece = torch.empty(max(words, 1), dtype=torch.int32, device=dev)
+            rc = L.coral_bamgpu_emit(h, piece.data_ptr(), None, stream)
+            if rc != 0:
+                raise fail("coral_bamgpu_emit", rc)
+            if words:
+                pieces.append(piece[:words])
+                total += words
+        cigar = torch.cat(pieces) if len(pieces) > 1 else (pieces[0] if pieces else torch.zeros(0, dtype=torch.int32, device=dev))
+        del pieces
+        dh = C.c_void_p()
+        _lib.check(L.coral_bamgpu_host(h, C.byref(dh)), "coral_bamgpu_host")
+        st, secs = (C.c_int64 * 3)(), C.c_double(0.0)
+        L.coral_bam_decode_stats(dh, st, C.byref(secs))
+        gst, gsecs = (C.c_int64 * 4)(), (C.c_double * 2)()
+        L.coral_bamgpu_stats(h, gst, gsecs)
+        LAST_DECODE.clear()
+        LAST_DECODE.update(seconds=float(gsecs[0]), compressed_bytes=int(st[0]), uncompressed_bytes=int(st[1]), blocks=int(st[2]),
+                           threads=int(n_threads), where="gpu", batches=int(gst[0]), rewalked_segments=int(gst[1]),
+                           nonacgt_records_fetched=int(gst[2]), batch_bytes=int(gst[3]), host_seconds=float(gsecs[1]),
+                           workspace_bytes=int(ws_bytes.value))
+        rec = _records_from_handle(L, dh, cigar, total)
+        del ws
+        return rec
+    finally:
+        L.coral_bamgpu_close(h)
 
 
 def write_bam_native(rec: Records, path: str, seed: int = 0, level: int = 1, n_threads: Optional[int] = None) -> None:

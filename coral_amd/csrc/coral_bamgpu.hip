@@ -1,0 +1,1137 @@
+// coral_bamgpu.hip — BAM (BGZF) decode ON THE GPU: compressed file bytes go over PCIe, everything else happens in HBM.
+//
+// Replaces, like coral_bam.cpp, what the reference gets from pysam.AlignmentFile(path, 'rb') + the whole-file fetch()
+// (/root/reference/src/infer_breakpoint_graph.py:65, :140-158), and produces the same SoA records as the CPU pipeline
+// (tests/test_bam_gpu.py compares the two field by field).  The CPU pipeline tops out at the host's inflate rate (zlib,
+// ~0.3 GB/s per core); here the host only moves compressed bytes:
+//
+//   feeder thread   pread(file) -> pinned staging -> BGZF block table of the batch -> H2D            (copy stream)
+//   k_bgzf_inflate  one wave per BGZF block: DEFLATE decode (coral_inflate_core.h) into the batch's buffer (inflate stream)
+//   k_bam_find      one wave per 128 KiB segment: first plausible record start (chained check) + hop along block_size
+//   k_bam_verify    one workgroup: follows the chain of segment landings from the batch's KNOWN first record; a segment
+//                   whose guess is not on the chain is re-walked exactly, so record boundaries never rest on a heuristic
+//   k_bam_starts    record start offsets, in file order
+//   k_bam_meta      one wave per record: fixed fields, tag walk (NM, SA, CG), sizes of what the record contributes
+//   (hipcub scans)  offsets of CIGAR ops (padded to 4), read-name bytes and SA text
+//   k_bam_emit      one wave per record: CIGAR -> padded SoA op array (+ reference / query lengths), SEQ scan for non-ACGT
+//                   codes, read name and SA text -> compact blobs for the host
+//   host            per batch, a few hundred bytes per record: read names -> ids, SA text -> numeric rows; the rare
+//                   records with non-ACGT bases are fetched whole and handled by the CPU pipeline's own routine.
+// Batches (<= 1 GiB inflated) are double-buffered: while batch k is parsed, batch k + 1 is inflated and k + 2 is read.
+// A record that straddles two batches is carried in front of the next batch's buffer.
+//
+// Multi-GPU: rank r of `world` decodes the BGZF blocks that start in its byte range of the file, with the
+// same first-record / last-record rule as coral_bam_decode_range, so consecutive ranges neither drop nor repeat a record.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "../../include/coral_hip.h"
+#include "coral_bam_common.h"
+#include "coral_inflate_core.h"
+
+using namespace coral_bam;
+
+namespace {
+
+#define WAVE 64
+#define SEG_BYTES (128ll << 10)          // granularity of the speculative record-start search
+#define CARRY_CAP (64ll << 20)           // room in front of a batch for the head of a straddling record
+#define COMP_SLACK 4096                  // readable bytes behind the compressed batch (the input window reads ahead)
+#define OVERHANG_BLOCKS 1024             // blocks behind a byte range its last record may straddle into (as coral_bam.cpp)
+
+struct BlockDesc {
+    uint32_t src_off;     // first DEFLATE byte, relative to the compressed batch
+    uint32_t src_len;     // DEFLATE bytes
+    uint32_t dst_off;     // first output byte, relative to the batch's first inflated byte
+    uint32_t isize;
+};
+
+// ---------------------------------------------------------------------------------------------
+// K_inflate
+// ---------------------------------------------------------------------------------------------
+struct DevWave {
+    int lane;
+    const uint32_t *words;      // dword-aligned start of the stream's window
+    const uint8_t *stream;      // first byte of the DEFLATE stream
+    long long stream_len;
+    long long base_dw;          // dword index (from `words`) the Inflater's `dwords` counts from
+    long long win;              // dword index of lane 0 of `cur`
+    uint32_t cur, nxt;          // lane i: words[win + i], words[win + 64 + i]
+    int idx;                    // next lane of `cur`
+    long long pulled;           // dwords handed out in total
+    uint8_t *out;
+    int cap, o, pfrom;
+    uint32_t pend, obase;
+
+    __device__ __forceinline__ uint32_t uni(uint32_t x) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+    __device__ __forceinline__ void load_window() {
+        cur = words[win + lane];
+        nxt = words[win + WAVE + lane];
+        idx = 0;
+    }
+    __device__ __forceinline__ uint32_t next_dword() {
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)cur, idx);
+        ++idx;
+        ++pulled;
+        if (idx == WAVE) {
+            cur = nxt;
+            win += WAVE;
+            nxt = words[win + WAVE + lane];
+            idx = 0;
+        }
+        return v;
+    }
+    __device__ __forceinline__ bool input_exhausted() const { return pulled * 4 > stream_len + 16; }
+    __device__ __forceinline__ void flush() {
+        if (pfrom < o) {
+            const int wb = (int)((obase + (uint32_t)pfrom) & ~63u) - (int)obase;
+            const int p = wb + lane;
+            if (p >= pfrom && p < o) out[p] = (uint8_t)pend;
+            pfrom = o;
+        }
+    }
+    __device__ __forceinline__ void put_literal(uint32_t b) {
+        const int l = (int)((obase + (uint32_t)o) & 63u);
+        pend = lane == l ? b : pend;
+        ++o;
+        if (((obase + (uint32_t)o) & 63u) == 0u) flush();
+    }
+    __device__ __forceinline__ bool copy_match(int len, int dist) {
+        if (dist > o) return false;
+        flush();
+        uint8_t *dstp = out + o;
+        const uint8_t *srcp = dstp - dist;
+        if (dist >= len) {                                   // source and destination do not overlap
+            for (int k = lane; k < len; k += WAVE) dstp[k] = srcp[k];
+        } else {                                             // a pattern of period `dist`: byte k = pattern[k mod dist]
+            const uint32_t m = ((1u << 20) + (uint32_t)dist - 1u) / (uint32_t)dist;      // exact for k < 258 (error < 258 / 2^20 < 1 / dist)
+            for (int k = lane; k < len; k += WAVE) {
+                const uint32_t q = ((uint32_t)k * m) >> 20;
+                dstp[k] = srcp[k - (int)(q * (uint32_t)dist)];
+            }
+        }
+        o += len;
+        pfrom = o;
+        return true;
+    }
+    __device__ __forceinline__ bool copy_stored(long long dwords, uint32_t n) {
+        const long long from = 4 * (base_dw + dwords) - (long long)(stream - (const uint8_t *)words);     // relative to the stream
+        if (from < 0 || from + (long long)n > stream_len) return false;
+        flush();
+        for (uint32_t k = (uint32_t)lane; k < n; k += WAVE) out[o + (int)k] = stream[from + k];
+        o += (int)n;
+        pfrom = o;
+        return true;
+    }
+    __device__ __forceinline__ uint32_t reset_input_after_stored(long long dwords, uint32_t n) {
+        const long long byte = 4 * (base_dw + dwords) + (long long)n;
+        base_dw = byte >> 2;
+        win = base_dw;
+        load_window();
+        return (uint32_t)(byte & 3) * 8u;
+    }
+    __device__ __forceinline__ int produced() const { return o; }
+    __device__ __forceinline__ int capacity() const { return cap; }
+    __device__ __forceinline__ void add_count(uint32_t *c) { atomicAdd(c, 1u); }
+    __device__ __forceinline__ void fence() {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
+#define INFL_WAVES 4
+__global__ __launch_bounds__(INFL_WAVES *WAVE) void k_bgzf_inflate(const uint8_t *__restrict__ comp, const BlockDesc *__restrict__ desc,
+                                                                     int n_blocks, uint8_t *out, int32_t *__restrict__ status) {
+    __shared__ coral_inflate::Tables tables[INFL_WAVES];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x * INFL_WAVES + wib;
+    if (b >= n_blocks) return;
+    const BlockDesc d = desc[b];
+    if (d.isize == 0) {
+        if (lane == 0) status[b] = 0;
+        return;
+    }
+    const uint8_t *stream = comp + d.src_off;
+    const uintptr_t a = (uintptr_t)stream;
+    DevWave w;
+    w.lane = lane;
+    w.words = (const uint32_t *)(a & ~(uintptr_t)3);
+    w.stream = stream;
+    w.stream_len = d.src_len;
+    w.base_dw = 0;
+    w.win = 0;
+    w.pulled = 0;
+    w.out = out + d.dst_off;
+    w.cap = (int)d.isize;
+    w.o = 0;
+    w.pfrom = 0;
+    w.pend = 0;
+    w.obase = (uint32_t)((uintptr_t)w.out & 63u);
+    w.load_window();
+    coral_inflate::Inflater<DevWave> inf(w, &tables[wib]);
+    const int rc = inf.run((int)(a & 3) * 8);
+    w.flush();
+    if (lane == 0) status[b] = rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// record boundaries
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
+
+// the plausibility test of coral_bam.cpp (plausible_record), on device memory
+__device__ __forceinline__ bool plausible(const uint8_t *buf, long long q, long long data_end, int n_ref, long long *len) {
+    const long long n = data_end - q;
+    if (n < 36) return false;
+    const uint8_t *p = buf + q;
+    const uint32_t bs = ld32(p);
+    if (bs < 34 || bs > (1u << 29)) return false;
+    const int32_t refID = (int32_t)ld32(p + 4), pos = (int32_t)ld32(p + 8);
+    const uint32_t l_name = p[12], n_cig = ld16(p + 16), l_seq = ld32(p + 20);
+    const int32_t mate = (int32_t)ld32(p + 24), mpos = (int32_t)ld32(p + 28);
+    if (refID < -1 || refID >= n_ref || mate < -1 || mate >= n_ref || pos < -1 || mpos < -1) return false;
+    if (l_name < 2 || l_seq > (1u << 29)) return false;
+    const unsigned long long fixed = 32ull + l_name + 4ull * n_cig + ((unsigned long long)l_seq + 1) / 2 + l_seq;
+    if (fixed > bs) return false;
+    if (n >= 36ll + l_name) {
+        const uint8_t *nm = p + 36;
+        if (nm[l_name - 1] != 0) return false;
+        for (uint32_t k = 0; k + 1 < l_name; ++k)
+            if (nm[k] < 33 || nm[k] > 126) return false;
+    }
+    *len = 4ll + bs;
+    return true;
+}
+
+// Hop along block_size from x while the record starts inside [.., seg_end) and in front of `limit` and is complete in the
+// batch.  Returns the landing position (first start not counted) and the count; *err is set for a record shorter than its
+// fixed fields.  The SAME function serves the speculative pass and the exact re-walk.
+__device__ __forceinline__ long long hop(const uint8_t *buf, long long x, long long seg_end, long long limit, long long data_end, int *count,
+                                         int *err) {
+    int c = 0;
+    while (x < seg_end && x < limit) {
+        if (x + 4 > data_end) break;
+        const long long len = 4ll + ld32(buf + x);
+        if (len < 36) { *err = 1; break; }
+        if (x + len > data_end) break;
+        ++c;
+        x += len;
+    }
+    *count = c;
+    return x;
+}
+
+// per segment s (buffer offsets [s * SEG, (s + 1) * SEG) clipped to [begin, data_end)): first plausible start, landing, count
+__global__ __launch_bounds__(256) void k_bam_find(const uint8_t *__restrict__ buf, long long begin, long long data_end, long long limit,
+                                                   int n_ref, int seg0, int n_seg, long long *__restrict__ seg_first,
+                                                   long long *__restrict__ seg_land, int32_t *__restrict__ seg_count,
+                                                   int32_t *__restrict__ seg_valid) {
+    const int lane = threadIdx.x & 63;
+    const int s = seg0 + (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (s >= seg0 + n_seg) return;
+    const long long a = max((long long)s * SEG_BYTES, begin), b = min((long long)(s + 1) * SEG_BYTES, data_end);
+    long long first = -1;
+    for (long long x0 = a; x0 < b; x0 += WAVE) {
+        const long long x = x0 + lane;
+        bool ok = false;
+        if (x < b && x + 36 <= data_end) {
+            long long q = x;
+            int chain = 0;
+            ok = true;
+            while (chain < 8 && q + 36 <= data_end) {
+                long long len;
+                if (!plausible(buf, q, data_end, n_ref, &len)) { ok = false; break; }
+                q += len;
+                ++chain;
+            }
+            ok = ok && chain >= 3;
+        }
+        const unsigned long long m = __ballot(ok);
+        if (m != 0ull) {
+            first = x0 + (long long)__builtin_ctzll(m);
+            break;
+        }
+    }
+    int count = 0, err = 0;
+    long long land = first;
+    if (first >= 0) land = hop(buf, first, b, limit, data_end, &count, &err);
+    if (lane == 0) {
+        seg_first[s] = err ? -1 : first;           // (a guess that runs into a malformed record is no guess)
+        seg_land[s] = land;
+        seg_count[s] = count;
+        seg_valid[s] = 0;
+    }
+}
+
+// result: [0] records, [1] carry position (first start not counted; may lie behind data_end), [2] done (limit reached),
+//         [3] error (1 = malformed record, 2 = no record start found while searching), [4] segments re-walked, [5] first start
+__global__ __launch_bounds__(WAVE) void k_bam_verify(const uint8_t *__restrict__ buf, long long known_start, long long begin, long long data_end,
+                                                      long long limit, int seg0, int n_seg, long long *__restrict__ seg_first,
+                                                      long long *__restrict__ seg_land, int32_t *__restrict__ seg_count,
+                                                      int32_t *__restrict__ seg_valid, long long *__restrict__ seg_base,
+                                                      long long *__restrict__ result) {
+    const int lane = threadIdx.x;
+    long long cur = known_start;
+    if (cur < 0) {                                   // first batch of a byte range: the lowest confirmed candidate
+        for (int s0 = seg0; s0 < seg0 + n_seg && cur < 0; s0 += WAVE) {
+            const int s = s0 + lane;
+            const long long f = s < seg0 + n_seg ? seg_first[s] : -1;
+            const unsigned long long m = __ballot(f >= 0);
+            if (m != 0ull) cur = __shfl(f, (int)__builtin_ctzll(m));
+        }
+        if (cur < 0) {
+            if (lane == 0) { result[0] = 0; result[1] = data_end; result[2] = 0; result[3] = 2; result[4] = 0; result[5] = -1; }
+            return;
+        }
+    }
+    const long long first_start = cur;
+    long long total = 0, fixups = 0;
+    int error = 0, done = 0;
+    for (;;) {
+        if (cur >= limit) { done = 1; break; }
+        if (cur + 4 > data_end) break;
+        const int s = (int)(cur / SEG_BYTES);
+        const long long seg_end = min((long long)(s + 1) * SEG_BYTES, data_end);
+        long long f = seg_first[s], land = seg_land[s];
+        int cnt = seg_count[s];
+        if (f != cur) {                              // the guess is not on the chain (or there was none): exact walk
+            int err = 0;
+            land = hop(buf, cur, seg_end, limit, data_end, &cnt, &err);
+            if (err) { error = 1; break; }
+            ++fixups;
+            if (lane == 0) { seg_first[s] = cur; seg_land[s] = land; seg_count[s] = cnt; }
+        }
+        if (lane == 0) { seg_base[s] = total; seg_valid[s] = 1; }
+        total += cnt;
+        cur = land;
+        if (cur >= limit) { done = 1; break; }
+        if (cur < seg_end) break;                    // stopped inside its segment: an incomplete record starts here
+    }
+    if (lane == 0) {
+        result[0] = total; result[1] = cur; result[2] = done; result[3] = error; result[4] = fixups; result[5] = first_start;
+    }
+}
+
+__global__ void k_bam_starts(const uint8_t *__restrict__ buf, int seg0, int n_seg, const long long *__restrict__ seg_first,
+                             const int32_t *__restrict__ seg_count, const int32_t *__restrict__ seg_valid,
+                             const long long *__restrict__ seg_base, long long *__restrict__ rec_start) {
+    const int s = seg0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= seg0 + n_seg || !seg_valid[s]) return;
+    long long x = seg_first[s];
+    const long long base = seg_base[s];
+    const int n = seg_count[s];
+    for (int i = 0; i < n; ++i) {
+        rec_start[base + i] = x;
+        x += 4ll + ld32(buf + x);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_meta: one wave per record
+// ---------------------------------------------------------------------------------------------
+struct MetaArrays {
+    int32_t *tid, *pos, *flag, *mapq, *l_seq, *nm, *n_cigar;       // what the host mirrors need (+ end, qlen from k_bam_emit)
+    long long *cig_src, *seq_src, *sa_src;                         // buffer offsets
+    long long *pad_ops, *name_len, *sa_len;                        // scan inputs (n + 1 entries, the last one 0)
+};
+
+enum { REC_ERR_SHORT = 1, REC_ERR_FIELDS = 2, REC_ERR_TAG_B = 3, REC_ERR_TAG_TYPE = 4, REC_ERR_TAG_OVERRUN = 5 };
+
+__global__ __launch_bounds__(256) void k_bam_meta(const uint8_t *__restrict__ buf, const long long *__restrict__ rec_start, long long n_rec,
+                                                   MetaArrays M, int32_t *__restrict__ error) {
+    const int lane = threadIdx.x & 63;
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i > n_rec) return;
+    if (i == n_rec) {                                               // the extra scan slot
+        if (lane == 0) { M.pad_ops[i] = 0; M.name_len[i] = 0; M.sa_len[i] = 0; }
+        return;
+    }
+    const long long x = rec_start[i];
+    const uint8_t *r = buf + x;
+    const uint32_t block_size = ld32(r);
+    const uint8_t *p = r + 4;
+    int err = 0;
+    int32_t refID = -1, pos = -1, nm = 0;
+    uint32_t l_read_name = 0, mapq = 0, n_cigar_op = 0, flag = 0, l_seq = 0;
+    long long cig_src = 0, seq_src = 0, sa_src = 0, sa_len = 0;
+    if (block_size < 32) {
+        err = REC_ERR_SHORT;
+    } else {
+        refID = (int32_t)ld32(p);
+        pos = (int32_t)ld32(p + 4);
+        l_read_name = p[8];
+        mapq = p[9];
+        n_cigar_op = ld16(p + 12);
+        flag = ld16(p + 14);
+        l_seq = ld32(p + 16);
+        const uint8_t *name = p + 32;
+        const uint8_t *cig = name + l_read_name;
+        const uint8_t *seq = cig + 4ull * n_cigar_op;
+        const uint8_t *qual = seq + ((unsigned long long)l_seq + 1) / 2;
+        const uint8_t *tags = qual + l_seq;
+        const uint8_t *endp = p + block_size;
+        if (tags > endp || l_read_name == 0) {
+            err = REC_ERR_FIELDS;
+        } else {
+            const uint8_t *cg = nullptr;
+            uint32_t cg_n = 0;
+            const uint8_t *t = tags;
+            while (t + 3 <= endp) {                                  // wave-uniform walk; Z / H strings are searched 64 bytes per step
+                const uint8_t ta = t[0], tb = t[1], ty = t[2];
+                const uint8_t *v = t + 3;
+                unsigned long long sz = 0;
+                if (ty == 'A' || ty == 'c' || ty == 'C') sz = 1;
+                else if (ty == 's' || ty == 'S') sz = 2;
+                else if (ty == 'i' || ty == 'I' || ty == 'f') sz = 4;
+                else if (ty == 'Z' || ty == 'H') {
+                    long long found = -1;
+                    for (const uint8_t *q = v; q < endp; q += WAVE) {
+                        const uint8_t c = (q + lane < endp) ? q[lane] : (uint8_t)1;
+                        const unsigned long long m = __ballot(c == 0);
+                        if (m != 0ull) { found = (q - v) + (long long)__builtin_ctzll(m); break; }
+                    }
+                    sz = found >= 0 ? (unsigned long long)found + 1 : (unsigned long long)(endp - v) + 1;
+                } else if (ty == 'B') {
+                    if (v + 5 > endp) { err = REC_ERR_TAG_B; break; }
+                    const uint8_t sub = v[0];
+                    const uint32_t cnt = ld32(v + 1);
+                    const unsigned long long es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                    if (ta == 'C' && tb == 'G' && sub == 'I') { cg = v + 5; cg_n = cnt; }
+                    sz = 5 + es * cnt;
+                } else { err = REC_ERR_TAG_TYPE; break; }
+                if (v + sz > endp) { err = REC_ERR_TAG_OVERRUN; break; }
+                if (ta == 'N' && tb == 'M') {
+                    if (ty == 'c') nm = (int8_t)v[0];
+                    else if (ty == 'C') nm = v[0];
+                    else if (ty == 's') nm = (int16_t)ld16(v);
+                    else if (ty == 'S') nm = (int32_t)ld16(v);
+                    else if (ty == 'i' || ty == 'I') nm = (int32_t)ld32(v);
+                } else if (ta == 'S' && tb == 'A' && ty == 'Z') {
+                    sa_src = v - buf;
+                    sa_len = (long long)sz;                          // with the terminating NUL
+                }
+                t = v + sz;
+            }
+            const uint8_t *cig_from = cig;
+            if (!err && cg && n_cigar_op == 2 && (ld32(cig) & 15u) == 4 && (ld32(cig) >> 4) == l_seq && (ld32(cig + 4) & 15u) == 3) {
+                cig_from = cg;                                       // long CIGAR in the CG tag (SAM spec §4.2.2)
+                n_cigar_op = cg_n;
+            }
+            cig_src = cig_from - buf;
+            seq_src = seq - buf;
+        }
+    }
+    if (lane == 0) {
+        if (err) atomicMax(error, err);
+        M.tid[i] = refID; M.pos[i] = pos; M.flag[i] = (int32_t)flag; M.mapq[i] = (int32_t)mapq; M.l_seq[i] = (int32_t)l_seq;
+        M.nm[i] = nm; M.n_cigar[i] = err ? 0 : (int32_t)n_cigar_op;
+        M.cig_src[i] = cig_src; M.seq_src[i] = seq_src; M.sa_src[i] = sa_src;
+        M.pad_ops[i] = err ? 0 : (long long)(((unsigned long long)n_cigar_op + 3ull) & ~3ull);
+        M.name_len[i] = err ? 0 : (long long)l_read_name;
+        M.sa_len[i] = err ? 0 : sa_len;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_emit: one wave per record
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bam_emit(const uint8_t *__restrict__ buf, const long long *__restrict__ rec_start, long long n_rec,
+                                                   MetaArrays M, const long long *__restrict__ cig_off, const long long *__restrict__ name_off,
+                                                   const long long *__restrict__ sa_off, uint32_t *__restrict__ cigar_dst,
+                                                   int32_t *__restrict__ end_out, int32_t *__restrict__ qlen_out, uint8_t *__restrict__ names,
+                                                   uint8_t *__restrict__ sa_text, int32_t *__restrict__ na_list, int32_t *__restrict__ na_count) {
+    const int lane = threadIdx.x & 63;
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i >= n_rec) return;
+    const int n = M.n_cigar[i];
+    const long long padded = M.pad_ops[i];
+    const uint8_t *cig = buf + M.cig_src[i];
+    uint32_t *dst = cigar_dst + cig_off[i];
+    long long rlen = 0, qinf = 0;
+    for (long long k = lane; k < padded; k += WAVE) {
+        const uint32_t w = k < n ? ld32(cig + 4 * k) : 15u;
+        dst[k] = w;
+        const uint32_t op = w & 15u, len = w >> 4;
+        rlen += ((0x18Du >> op) & 1u) ? len : 0;                      // M D N = X
+        qinf += ((0x1B3u >> op) & 1u) ? len : 0;                      // M I S H = X
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        rlen += __shfl_xor(rlen, d);
+        qinf += __shfl_xor(qinf, d);
+    }
+    const int32_t flag = M.flag[i], l_seq = M.l_seq[i], pos = M.pos[i];
+    if ((flag & 4) || n == 0) rlen = 0;                               // htslib bam_endpos
+    if (lane == 0) {
+        end_out[i] = pos + (int32_t)(rlen > 0 ? rlen : 1);
+        qlen_out[i] = l_seq > 0 ? l_seq : (int32_t)qinf;
+    }
+    // read name (with its NUL) and SA text (with its NUL)
+    {
+        const uint8_t *src = buf + rec_start[i] + 36;
+        const long long nl = M.name_len[i];
+        uint8_t *d = names + name_off[i];
+        for (long long k = lane; k < nl; k += WAVE) d[k] = src[k];
+        const long long sl = M.sa_len[i];
+        if (sl) {
+            const uint8_t *s = buf + M.sa_src[i];
+            uint8_t *e = sa_text + sa_off[i];
+            for (long long k = lane; k < sl; k += WAVE) e[k] = s[k];
+        }
+    }
+    // aligned non-ACGT bases are rare: only FIND the records that have any non-ACGT code (pysam count_coverage counts A/C/G/T)
+    if (l_seq > 0 && !(flag & 4) && n > 0) {
+        const uint8_t *seq = buf + M.seq_src[i];
+        const long long full = l_seq / 2;
+        uint32_t bad = 0;
+        const long long words = full / 4;
+        for (long long k = lane; k < words; k += WAVE) {
+            const uint32_t x = ld32(seq + 4 * k);
+            const uint32_t lo = x & 0x0f0f0f0fu, hi = (x >> 4) & 0x0f0f0f0fu;
+            const uint32_t tl = (lo | 0x10101010u) - 0x01010101u, th = (hi | 0x10101010u) - 0x01010101u;
+            bad |= (tl & lo & 0x0f0f0f0fu) | (~tl & 0x10101010u) | (th & hi & 0x0f0f0f0fu) | (~th & 0x10101010u);
+        }
+        for (long long k = words * 4 + lane; k < full; k += WAVE) {
+            const uint32_t h = seq[k] >> 4, l = seq[k] & 15u;
+            bad |= (h == 0 || (h & (h - 1))) | (l == 0 || (l & (l - 1)));
+        }
+        if ((l_seq & 1) && lane == 0) {
+            const uint32_t h = seq[full] >> 4;
+            bad |= (h == 0 || (h & (h - 1)));
+        }
+        if (__ballot(bad != 0) != 0ull && lane == 0) na_list[atomicAdd(na_count, 1)] = (int32_t)i;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct BatchInfo {
+    int n_blocks = 0;
+    uint64_t file_off = 0, comp_bytes = 0, infl_bytes = 0;
+    uint64_t ubase = 0;              // offset of the batch's first inflated byte in this range's uncompressed stream
+    bool has_limit = false;          // the next byte range begins at or in front of this batch's end:
+    long long limit_rel = 0;         //   at this offset from the batch's first inflated byte (negative: in an earlier batch)
+    bool last = false;               // nothing follows
+};
+
+struct GpuDecoder {
+    MappedFile f;
+    Decoded D;
+    RefIds ref_id;
+    size_t hdr_bytes = 0;
+    int rank = 0, world = 1, n_threads = 1, device = 0;
+    uint64_t byte_lo = 0, byte_hi = 0, first_block = 0;
+    bool last_rank = true;
+    std::string error;
+    // capacities
+    size_t infl_cap = 0, comp_cap = 0, max_blocks = 0, rec_cap = 0, nseg_cap = 0;
+    size_t ws_bytes = 0;
+    // device workspace (carved from the caller's allocation)
+    uint8_t *d_comp[2] = {nullptr, nullptr}, *d_infl[2] = {nullptr, nullptr};
+    BlockDesc *d_desc[2] = {nullptr, nullptr};
+    int32_t *d_status[2] = {nullptr, nullptr};
+    long long *d_seg_first = nullptr, *d_seg_land = nullptr, *d_seg_base = nullptr, *d_result = nullptr, *d_rec_start = nullptr;
+    int32_t *d_seg_count = nullptr, *d_seg_valid = nullptr, *d_error = nullptr, *d_na_list = nullptr, *d_na_count = nullptr;
+    MetaArrays M{};
+    long long *d_cig_off = nullptr, *d_name_off = nullptr, *d_sa_off = nullptr;
+    int32_t *d_end = nullptr, *d_qlen = nullptr;
+    uint8_t *d_names = nullptr, *d_sa_text = nullptr;
+    void *d_scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0, names_cap = 0, sa_cap = 0;
+    // pinned staging + streams
+    uint8_t *h_stage[2] = {nullptr, nullptr};
+    hipStream_t s_copy = nullptr, s_infl = nullptr;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_infl[2] = {nullptr, nullptr}, ev_parsed[2] = {nullptr, nullptr};
+    // feeder
+    std::thread feeder;
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<BatchInfo> staged;            // batches whose H2D has been issued
+    bool feeder_done = false, stop = false;
+    int inflate_launched = 0;                 // batches whose inflate kernel has been enqueued
+    std::string feeder_error;
+    // walk state
+    int k = 0;                                // next batch to parse
+    bool searching = false, finished = false;
+    long long known_start = 0;                // buffer offset of the first record of batch k (CARRY_CAP-based)
+    long long carry_len = 0;                  // bytes carried in front of batch k
+    // the batch between next() and emit()
+    BatchInfo cur;
+    long long cur_n_rec = 0, cur_ops = 0, cur_name_bytes = 0, cur_sa_bytes = 0;
+    bool have_cur = false;
+    std::unordered_map<std::string, int32_t> name_id;
+    // statistics
+    double t_open = 0, seconds = 0, host_seconds = 0;
+    int64_t fixups = 0, n_batches = 0, na_records = 0;
+    std::chrono::steady_clock::time_point t_start;
+
+    ~GpuDecoder() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv.notify_all();
+        if (feeder.joinable()) feeder.join();
+        for (int i = 0; i < 2; ++i) {
+            if (h_stage[i]) (void)hipHostFree(h_stage[i]);
+            if (ev_h2d[i]) (void)hipEventDestroy(ev_h2d[i]);
+            if (ev_infl[i]) (void)hipEventDestroy(ev_infl[i]);
+            if (ev_parsed[i]) (void)hipEventDestroy(ev_parsed[i]);
+        }
+        if (s_copy) (void)hipStreamDestroy(s_copy);
+        if (s_infl) (void)hipStreamDestroy(s_infl);
+    }
+};
+
+#define HIP_OK(call, what)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            G->error = std::string(what) + ": " + hipGetErrorString(e_);                    \
+            return false;                                                                   \
+        }                                                                                   \
+    } while (0)
+
+// parallel pread of [off, off + n) into dst
+bool read_range(int fd, uint64_t off, size_t n, uint8_t *dst, int n_threads) {
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, n / (4u << 20) + 1));
+    std::atomic<bool> bad{false};
+    auto work = [&](int t) {
+        size_t a = n * (size_t)t / (size_t)nt, b = n * (size_t)(t + 1) / (size_t)nt;
+        while (a < b) {
+            const ssize_t got = pread(fd, dst + a, b - a, (off_t)(off + a));
+            if (got <= 0) { bad = true; return; }
+            a += (size_t)got;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &t : th) t.join();
+    return !bad;
+}
+
+// The feeder: cuts the byte range into batches (whole BGZF blocks, <= infl_cap inflated and <= comp_cap compressed bytes),
+// reads each into pinned memory, builds its block table and sends both to the device.
+void feeder_main(GpuDecoder *G) {
+    (void)hipSetDevice(G->device);
+    uint64_t at = G->first_block;
+    uint64_t ubase = 0;
+    long long own_bytes = -1;                 // known once the first block of the next range has been seen
+    size_t overhang_left = OVERHANG_BLOCKS;
+    int kb = 0;
+    auto fail = [&](const std::string &msg) {
+        std::lock_guard<std::mutex> lk(G->m);
+        G->feeder_error = msg;
+        G->feeder_done = true;
+        G->cv.notify_all();
+    };
+    for (;;) {
+        const int slot = kb & 1;
+        if (at >= G->f.size || (own_bytes >= 0 && overhang_left == 0)) break;
+        {   // the slot's device buffers are free once the inflate of batch kb - 2 has run
+            std::unique_lock<std::mutex> lk(G->m);
+            G->cv.wait(lk, [&] { return G->stop || G->inflate_launched >= kb - 1; });
+            if (G->stop) return;
+        }
+        if (kb >= 2 && hipEventSynchronize(G->ev_infl[slot]) != hipSuccess) return fail("hipEventSynchronize failed in the feeder");
+        const size_t want = (size_t)std::min<uint64_t>(G->comp_cap, G->f.size - at);
+        uint8_t *stage = G->h_stage[slot];
+        const size_t desc_bytes = up256(G->max_blocks * sizeof(BlockDesc));
+        uint8_t *data = stage + desc_bytes;
+        if (!read_range(G->f.fd, at, want, data, G->n_threads)) return fail("reading the BAM file failed");
+        BlockDesc *desc = (BlockDesc *)stage;
+        BatchInfo bi;
+        bi.file_off = at;
+        bi.ubase = ubase;
+        size_t p = 0;
+        uint64_t infl = 0;
+        while (p < want && (size_t)bi.n_blocks < G->max_blocks) {
+            Block b;
+            if (!bgzf_header(data + p, want - p, b)) {
+                if (want - p >= 65536 + 26 || at + want >= G->f.size) return fail("not a BGZF block");
+                break;                                             // the block continues behind what was read
+            }
+            if (infl + b.isize > G->infl_cap) break;
+            const bool owned = at + p < G->byte_hi;
+            if (!owned) {
+                if (own_bytes < 0) {
+                    own_bytes = (long long)(ubase + infl);
+                }
+                if (overhang_left == 0) break;
+                --overhang_left;
+            }
+            BlockDesc &d = desc[bi.n_blocks++];
+            d.src_off = (uint32_t)(p + b.hdr);
+            d.src_len = b.csize - b.hdr - 8;
+            d.dst_off = (uint32_t)infl;
+            d.isize = b.isize;
+            infl += b.isize;
+            p += b.csize;
+            if (owned) { G->D.compressed_bytes += b.csize; G->D.uncompressed_bytes += b.isize; ++G->D.n_blocks; }
+        }
+        if (bi.n_blocks == 0) return fail("a BGZF block does not fit the batch buffers");
+        bi.comp_bytes = p;
+        bi.infl_bytes = infl;
+        if (own_bytes >= 0) {
+            bi.has_limit = true;
+            bi.limit_rel = own_bytes - (long long)ubase;
+        }
+        at += p;
+        ubase += infl;
+        bi.last = at >= G->f.size || (own_bytes >= 0 && overhang_left == 0);
+        if (hipMemcpyAsync(G->d_desc[slot], desc, (size_t)bi.n_blocks * sizeof(BlockDesc), hipMemcpyHostToDevice, G->s_copy) != hipSuccess ||
+            hipMemcpyAsync(G->d_comp[slot], data, p, hipMemcpyHostToDevice, G->s_copy) != hipSuccess ||
+            hipEventRecord(G->ev_h2d[slot], G->s_copy) != hipSuccess)
+            return fail("host-to-device copy of a compressed batch failed");
+        // (the staging slot is reused two batches later, after the inflate of this batch — hence after this copy — has run)
+        {
+            std::lock_guard<std::mutex> lk(G->m);
+            G->staged.push_back(bi);
+        }
+        G->cv.notify_all();
+        ++kb;
+        if (bi.last) break;
+    }
+    {
+        std::lock_guard<std::mutex> lk(G->m);
+        G->feeder_done = true;
+    }
+    G->cv.notify_all();
+}
+
+bool carve(GpuDecoder *G, void *ws, size_t bytes) {
+    uint8_t *p = (uint8_t *)ws;
+    size_t used = 0;
+    auto take = [&](size_t n) -> void * {
+        void *q = p + used;
+        used += up256(n);
+        return q;
+    };
+    for (int i = 0; i < 2; ++i) {
+        G->d_comp[i] = (uint8_t *)take(G->comp_cap + COMP_SLACK);
+        G->d_infl[i] = (uint8_t *)take((size_t)CARRY_CAP + G->infl_cap + COMP_SLACK);
+        G->d_desc[i] = (BlockDesc *)take(G->max_blocks * sizeof(BlockDesc));
+        G->d_status[i] = (int32_t *)take(G->max_blocks * 4);
+    }
+    const size_t ns = G->nseg_cap, nr = G->rec_cap + 1;
+    G->d_seg_first = (long long *)take(ns * 8);
+    G->d_seg_land = (long long *)take(ns * 8);
+    G->d_seg_base = (long long *)take(ns * 8);
+    G->d_seg_count = (int32_t *)take(ns * 4);
+    G->d_seg_valid = (int32_t *)take(ns * 4);
+    G->d_result = (long long *)take(64);
+    G->d_error = (int32_t *)take(16);
+    G->d_na_count = (int32_t *)take(16);
+    G->d_rec_start = (long long *)take(nr * 8);
+    G->M.tid = (int32_t *)take(nr * 4); G->M.pos = (int32_t *)take(nr * 4); G->M.flag = (int32_t *)take(nr * 4);
+    G->M.mapq = (int32_t *)take(nr * 4); G->M.l_seq = (int32_t *)take(nr * 4); G->M.nm = (int32_t *)take(nr * 4);
+    G->M.n_cigar = (int32_t *)take(nr * 4);
+    G->M.cig_src = (long long *)take(nr * 8); G->M.seq_src = (long long *)take(nr * 8); G->M.sa_src = (long long *)take(nr * 8);
+    G->M.pad_ops = (long long *)take(nr * 8); G->M.name_len = (long long *)take(nr * 8); G->M.sa_len = (long long *)take(nr * 8);
+    G->d_cig_off = (long long *)take(nr * 8); G->d_name_off = (long long *)take(nr * 8); G->d_sa_off = (long long *)take(nr * 8);
+    G->d_end = (int32_t *)take(nr * 4); G->d_qlen = (int32_t *)take(nr * 4);
+    G->d_na_list = (int32_t *)take(nr * 4);
+    G->d_scan_tmp = take(G->scan_tmp_bytes);
+    // read names and SA text of one batch can never exceed its inflated bytes (+ what was carried)
+    G->names_cap = G->sa_cap = (size_t)CARRY_CAP + G->infl_cap;
+    G->d_names = (uint8_t *)take(G->names_cap);
+    G->d_sa_text = (uint8_t *)take(G->sa_cap);
+    if (ws && used > bytes) return false;
+    G->ws_bytes = used;
+    return true;
+}
+
+bool launch_inflate(GpuDecoder *G, int kb, const BatchInfo &bi) {
+    const int slot = kb & 1;
+    HIP_OK(hipStreamWaitEvent(G->s_infl, G->ev_h2d[slot], 0), "hipStreamWaitEvent");
+    if (kb >= 2) HIP_OK(hipStreamWaitEvent(G->s_infl, G->ev_parsed[slot], 0), "hipStreamWaitEvent");     // the buffer's previous batch has been parsed
+    const int grid = (bi.n_blocks + INFL_WAVES - 1) / INFL_WAVES;
+    hipLaunchKernelGGL(k_bgzf_inflate, dim3(grid), dim3(INFL_WAVES * WAVE), 0, G->s_infl, G->d_comp[slot], G->d_desc[slot], bi.n_blocks,
+                       G->d_infl[slot] + CARRY_CAP, G->d_status[slot]);
+    HIP_OK(hipGetLastError(), "k_bgzf_inflate");
+    HIP_OK(hipEventRecord(G->ev_infl[slot], G->s_infl), "hipEventRecord");
+    {
+        std::lock_guard<std::mutex> lk(G->m);
+        G->inflate_launched = kb + 1;
+    }
+    G->cv.notify_all();
+    return true;
+}
+
+// wait until batch kb has been staged; false = there is no such batch (or the feeder failed: G->error set)
+bool wait_staged(GpuDecoder *G, int kb, BatchInfo *bi) {
+    std::unique_lock<std::mutex> lk(G->m);
+    G->cv.wait(lk, [&] { return (int)G->staged.size() > kb || G->feeder_done; });
+    if (!G->feeder_error.empty()) { G->error = G->feeder_error; return false; }
+    if ((int)G->staged.size() <= kb) return false;
+    *bi = G->staged[(size_t)kb];
+    return true;
+}
+
+const char *rec_error_text(int e) {
+    switch (e) {
+        case REC_ERR_SHORT: return "record shorter than its fixed fields";
+        case REC_ERR_FIELDS: return "record fields overrun the record";
+        case REC_ERR_TAG_B: return "truncated B tag";
+        case REC_ERR_TAG_TYPE: return "unknown tag type";
+        case REC_ERR_TAG_OVERRUN: return "tag overruns the record";
+    }
+    return "malformed record";
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" int coral_bamgpu_open(const char *path, int32_t n_threads, int32_t rank, int32_t world, int64_t batch_bytes, void **handle,
+                                 int64_t *workspace_bytes) {
+    if (!path || !handle || !workspace_bytes || world < 1 || rank < 0 || rank >= world) return CORAL_ERR_ARG;
+    std::unique_ptr<GpuDecoder> G(new GpuDecoder());
+    G->t_start = std::chrono::steady_clock::now();
+    if (!G->f.open(path, G->error) || !read_bam_header(G->f, G->D, G->ref_id, &G->hdr_bytes)) {
+        set_error(G->error.empty() ? G->D.error : G->error);
+        return CORAL_ERR_FORMAT;
+    }
+    G->rank = rank;
+    G->world = world;
+    G->n_threads = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
+    G->last_rank = rank == world - 1;
+    G->byte_lo = rank == 0 ? 0 : G->f.size / (uint64_t)world * (uint64_t)rank;
+    G->byte_hi = G->last_rank ? G->f.size : G->f.size / (uint64_t)world * (uint64_t)(rank + 1);
+    G->first_block = 0;
+    if (rank > 0 && !find_block(G->f, G->byte_lo, &G->first_block)) G->first_block = G->f.size;
+    if (G->first_block >= G->byte_hi) G->first_block = G->f.size;          // no block starts in this range: nothing to do
+    G->searching = rank > 0;
+    // batch size: at most `batch_bytes` inflated (default 1 GiB), no more than the range can need
+    const uint64_t range = G->byte_hi > G->first_block ? G->byte_hi - G->first_block : 0;
+    uint64_t cap = batch_bytes > 0 ? (uint64_t)batch_bytes : (1ull << 30);
+    cap = std::min<uint64_t>(cap, std::max<uint64_t>(16ull << 20, (range * 6 + (64ull << 20) + 0xffff) & ~0xffffull));
+    G->infl_cap = (size_t)std::max<uint64_t>(cap, 1ull << 20);
+    G->comp_cap = std::max<size_t>(G->infl_cap / 2, 1u << 20);
+    G->max_blocks = G->comp_cap / 28 < (1u << 22) ? std::max<size_t>(G->comp_cap / 28, 64) : (1u << 22);   // a block is >= 28 bytes
+    if (G->max_blocks > G->infl_cap / 256 + 65536) G->max_blocks = G->infl_cap / 256 + 65536;
+    G->rec_cap = ((size_t)CARRY_CAP + G->infl_cap) / 36 + 2;
+    G->nseg_cap = ((size_t)CARRY_CAP + G->infl_cap) / (size_t)SEG_BYTES + 4;
+    size_t tmp = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, (long long *)nullptr, (long long *)nullptr, (int)std::min<size_t>(G->rec_cap + 1, 0x7fffffff));
+    G->scan_tmp_bytes = tmp + 256;
+    carve(G.get(), nullptr, 0);
+    G->known_start = CARRY_CAP + (long long)(rank == 0 ? G->hdr_bytes : 0);
+    *workspace_bytes = (int64_t)G->ws_bytes;
+    *handle = G.release();
+    return CORAL_OK;
+}
+
+extern "C" int coral_bamgpu_start(void *handle, void *workspace, int64_t workspace_bytes) {
+    GpuDecoder *G = (GpuDecoder *)handle;
+    if (!G || !workspace || workspace_bytes < (int64_t)G->ws_bytes || (((uintptr_t)workspace) & 255)) return CORAL_ERR_ARG;
+    auto bad = [&](const char *what, hipError_t e) {
+        set_error(std::string(what) + ": " + hipGetErrorString(e));
+        return CORAL_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipGetDevice(&G->device)) != hipSuccess) return bad("hipGetDevice", e);
+    carve(G, workspace, (size_t)workspace_bytes);
+    const size_t stage_bytes = up256(G->max_blocks * sizeof(BlockDesc)) + G->comp_cap;
+    for (int i = 0; i < 2; ++i) {
+        if ((e = hipHostMalloc((void **)&G->h_stage[i], stage_bytes, hipHostMallocDefault)) != hipSuccess) return bad("hipHostMalloc", e);
+        if ((e = hipEventCreateWithFlags(&G->ev_h2d[i], hipEventDisableTiming)) != hipSuccess) return bad("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&G->ev_infl[i], hipEventDisableTiming)) != hipSuccess) return bad("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&G->ev_parsed[i], hipEventDisableTiming)) != hipSuccess) return bad("hipEventCreate", e);
+    }
+    if ((e = hipStreamCreateWithFlags(&G->s_copy, hipStreamNonBlocking)) != hipSuccess) return bad("hipStreamCreate", e);
+    if ((e = hipStreamCreateWithFlags(&G->s_infl, hipStreamNonBlocking)) != hipSuccess) return bad("hipStreamCreate", e);
+    G->feeder = std::thread(feeder_main, G);
+    // inflate of batch 0 starts as soon as it is staged
+    BatchInfo b0;
+    if (wait_staged(G, 0, &b0)) {
+        if (!launch_inflate(G, 0, b0)) { set_error(G->error); return CORAL_ERR_HIP; }
+    } else if (!G->error.empty()) {
+        set_error(G->error);
+        return CORAL_ERR_FORMAT;
+    }
+    return CORAL_OK;
+}
+
+// Parse the next batch up to the sizes of what it contributes.  out: [0] records, [1] padded CIGAR ops, [2] 1 = a batch was
+// parsed (call coral_bamgpu_emit next), 0 = the file is done.
+extern "C" int coral_bamgpu_next(void *handle, int64_t out[4], void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GpuDecoder *G = (GpuDecoder *)handle;
+    if (!G || !out) return CORAL_ERR_ARG;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (G->have_cur) { set_error("coral_bamgpu_next: the previous batch has not been emitted"); return CORAL_ERR_ARG; }
+    auto fail = [&](int code) {
+        set_error(G->error);
+        return code;
+    };
+    if (G->finished) return CORAL_OK;
+    BatchInfo bi;
+    if (!wait_staged(G, G->k, &bi)) {
+        if (!G->error.empty()) return fail(CORAL_ERR_FORMAT);
+        if (G->carry_len > 0 && !G->searching) { G->error = G->last_rank ? "truncated record at the end of the file" : "a record straddles further than the supported overhang"; return fail(CORAL_ERR_FORMAT); }
+        G->finished = true;
+        return CORAL_OK;
+    }
+    const int kb = G->k, slot = kb & 1;
+    uint8_t *buf = G->d_infl[slot];
+    if (G->inflate_launched < kb + 1 && !launch_inflate(G, kb, bi)) return fail(CORAL_ERR_HIP);      // (the feeder was behind)
+    // the inflate of the batch after this one runs while this one is parsed
+    BatchInfo nb;
+    bool have_next = false;
+    {
+        std::unique_lock<std::mutex> lk(G->m);
+        have_next = (int)G->staged.size() > kb + 1;
+        if (have_next) nb = G->staged[(size_t)kb + 1];
+    }
+    // this batch's inflate must be complete before the parse kernels read its bytes
+    if (hipStreamWaitEvent(stream, G->ev_infl[slot], 0) != hipSuccess) { G->error = "hipStreamWaitEvent failed"; return fail(CORAL_ERR_HIP); }
+    const long long data_end = CARRY_CAP + (long long)bi.infl_bytes;
+    const long long begin = G->searching ? (long long)CARRY_CAP : std::min(G->known_start, data_end);
+    const long long limit = (G->last_rank || !bi.has_limit) ? (1ll << 62) : (long long)CARRY_CAP + bi.limit_rel;
+    const int seg0 = (int)(begin / SEG_BYTES);
+    const int n_seg = (int)((data_end + SEG_BYTES - 1) / SEG_BYTES) - seg0;
+    const int n_ref = (int)G->D.ref_names.size();
+    long long res[6] = {0, 0, 0, 0, 0, 0};
+    if (n_seg > 0) {
+        hipLaunchKernelGGL(k_bam_find, dim3((n_seg + 3) / 4), dim3(256), 0, stream, buf, begin, data_end, limit, n_ref, seg0, n_seg, G->d_seg_first,
+                           G->d_seg_land, G->d_seg_count, G->d_seg_valid);
+        hipLaunchKernelGGL(k_bam_verify, dim3(1), dim3(WAVE), 0, stream, buf, G->searching ? -1ll : G->known_start, begin, data_end, limit, seg0, n_seg,
+                           G->d_seg_first, G->d_seg_land, G->d_seg_count, G->d_seg_valid, G->d_seg_base, G->d_result);
+    }
+    if (have_next && !launch_inflate(G, kb + 1, nb)) return fail(CORAL_ERR_HIP);
+    int32_t status_bad = 0;
+    if (n_seg > 0) {
+        if (hipMemcpyAsync(res, G->d_result, sizeof(res), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+            G->error = std::string("record walk failed: ") + hipGetErrorString(hipGetLastError());
+            return fail(CORAL_ERR_HIP);
+        }
+    } else {
+        res[1] = G->known_start;
+        if (hipStreamSynchronize(stream) != hipSuccess) { G->error = "hipStreamSynchronize failed"; return fail(CORAL_ERR_HIP); }
+    }
+    {   // every block of the batch must have inflated cleanly
+        std::vector<int32_t> st((size_t)bi.n_blocks);
+        if (hipMemcpy(st.data(), G->d_status[slot], st.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { G->error = "hipMemcpy failed"; return fail(CORAL_ERR_HIP); }
+        for (int32_t s : st) if (s != 0) { status_bad = s; break; }
+        if (status_bad) { G->error = "inflate failed (corrupt BGZF block), code " + std::to_string(status_bad); return fail(CORAL_ERR_FORMAT); }
+    }
+    if (res[3] == 1) { G->error = "record shorter than its fixed fields"; return fail(CORAL_ERR_FORMAT); }
+    if (res[3] == 2) { G->error = "no record start found in the first batch of the byte range"; return fail(CORAL_ERR_FORMAT); }
+    const long long n_rec = res[0], carry_pos = res[1];
+    G->fixups += res[4];
+    if (n_rec > (long long)G->rec_cap) { G->error = "more records in a batch than its workspace holds"; return fail(CORAL_ERR_FORMAT); }
+    G->searching = false;
+    G->cur = bi;
+    G->cur_n_rec = n_rec;
+    G->cur_ops = G->cur_name_bytes = G->cur_sa_bytes = 0;
+    if (n_rec > 0) {
+        hipLaunchKernelGGL(k_bam_starts, dim3((n_seg + 255) / 256), dim3(256), 0, stream, buf, seg0, n_seg, G->d_seg_first, G->d_seg_count, G->d_seg_valid,
+                           G->d_seg_base, G->d_rec_start);
+        (void)hipMemsetAsync(G->d_error, 0, 4, stream);
+        const long long waves = n_rec + 1;
+        hipLaunchKernelGGL(k_bam_meta, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, buf, G->d_rec_start, n_rec, G->M, G->d_error);
+        size_t tmp = G->scan_tmp_bytes;
+        (void)hipcub::DeviceScan::ExclusiveSum(G->d_scan_tmp, tmp, G->M.pad_ops, G->d_cig_off, (int)(n_rec + 1), stream);
+        tmp = G->scan_tmp_bytes;
+        (void)hipcub::DeviceScan::ExclusiveSum(G->d_scan_tmp, tmp, G->M.name_len, G->d_name_off, (int)(n_rec + 1), stream);
+        tmp = G->scan_tmp_bytes;
+        (void)hipcub::DeviceScan::ExclusiveSum(G->d_scan_tmp, tmp, G->M.sa_len, G->d_sa_off, (int)(n_rec + 1), stream);
+        long long totals[3] = {0, 0, 0};
+        int32_t rec_err = 0;
+        if (hipMemcpyAsync(&totals[0], G->d_cig_off + n_rec, 8, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipMemcpyAsync(&totals[1], G->d_name_off + n_rec, 8, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipMemcpyAsync(&totals[2], G->d_sa_off + n_rec, 8, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipMemcpyAsync(&rec_err, G->d_error, 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+            G->error = std::string("record parse failed: ") + hipGetErrorString(hipGetLastError());
+            return fail(CORAL_ERR_HIP);
+        }
+        if (rec_err) { G->error = rec_error_text(rec_err); return fail(CORAL_ERR_FORMAT); }
+        G->cur_ops = totals[0];
+        G->cur_name_bytes = totals[1];
+        G->cur_sa_bytes = totals[2];
+    }
+    // what the next batch starts with
+    const bool done = res[2] != 0;
+    if (done) {
+        G->finished = true;
+        G->carry_len = 0;
+    } else if (carry_pos < data_end) {
+        G->carry_len = data_end - carry_pos;
+        if (G->carry_len > CARRY_CAP) { G->error = "a record larger than 256 MiB straddles two batches"; return fail(CORAL_ERR_FORMAT); }
+        G->known_start = CARRY_CAP - G->carry_len;
+    } else {
+        G->carry_len = 0;
+        G->known_start = CARRY_CAP + (carry_pos - data_end);
+    }
+    if (bi.last && !done) {
+        if (G->carry_len > 0) { G->error = G->last_rank ? "truncated record at the end of the file" : "a record straddles further than the supported overhang"; return fail(CORAL_ERR_FORMAT); }
+        G->finished = true;
+    }
+    G->have_cur = true;
+    ++G->n_batches;
+    out[0] = n_rec;
+    out[1] = G->cur_ops;
+    out[2] = 1;
+    return CORAL_OK;
+}
+
+// Write the batch's CIGAR ops (padded SoA, `cigar_dst` device pointer with room for out[1] of coral_bamgpu_next words) and,
+// if wanted, the batch-local op offsets (`cigar_off_dst`, device, n_rec + 1 int64; may be NULL — the offsets over the whole
+// file are part of the host-side result), and take the batch's host-side fields in.
+extern "C" int coral_bamgpu_emit(void *handle, uint32_t *cigar_dst, int64_t *cigar_off_dst, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GpuDecoder *G = (GpuDecoder *)handle;
+    if (!G || !G->have_cur) return CORAL_ERR_ARG;
+    auto fail = [&](int code, const std::string &msg) {
+        set_error(msg);
+        return code;
+    };
+    const int kb = G->k, slot = kb & 1;
+    uint8_t *buf = G->d_infl[slot];
+    const long long n = G->cur_n_rec;
+    Decoded &D = G->D;
+    if (n > 0) {
+        if (G->cur_ops > 0 && !cigar_dst) return CORAL_ERR_ARG;
+        (void)hipMemsetAsync(G->d_na_count, 0, 4, stream);
+        hipLaunchKernelGGL(k_bam_emit, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, buf, G->d_rec_start, n, G->M, G->d_cig_off, G->d_name_off,
+                           G->d_sa_off, cigar_dst, G->d_end, G->d_qlen, G->d_names, G->d_sa_text, G->d_na_list, G->d_na_count);
+        if (cigar_off_dst && hipMemcpyAsync(cigar_off_dst, G->d_cig_off, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+            return fail(CORAL_ERR_HIP, "device copy of the op offsets failed");
+    }
+    // the head of a straddling record moves in front of the next batch's bytes (same stream: after the kernels above)
+    if (G->carry_len > 0 && !G->finished) {
+        const long long data_end = CARRY_CAP + (long long)G->cur.infl_bytes;
+        if (hipMemcpyAsync(G->d_infl[slot ^ 1] + CARRY_CAP - G->carry_len, buf + data_end - G->carry_len, (size_t)G->carry_len, hipMemcpyDeviceToDevice,
+                           stream) != hipSuccess)
+            return fail(CORAL_ERR_HIP, "device copy of the carried bytes failed");
+    }
+    const auto t_host0 = std::chrono::steady_clock::now();
+    if (n > 0) {
+        const size_t base = D.tid.size();
+        auto grow = [&](std::vector<int32_t> &v) { v.resize(base + (size_t)n); return v.data() + base; };
+        int32_t *tid = grow(D.tid), *pos = grow(D.pos), *end = grow(D.end), *flag = grow(D.flag), *mapq = grow(D.mapq), *qlen = grow(D.qlen),
+                *has_seq = grow(D.has_seq), *nm = grow(D.nm), *n_cigar = grow(D.n_cigar);
+        std::vector<long long> pad((size_t)n), name_off((size_t)n + 1), sa_off((size_t)n + 1);
+        std::vector<uint8_t> names((size_t)G->cur_name_bytes), sa_text((size_t)G->cur_sa_bytes);
+        int32_t na_count = 0;
+        auto get = [&](void *dst, const void *src, size_t bytes) { return bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream) == hipSuccess; };
+        const size_t n4 = (size_t)n * 4;
+        bool ok = get(tid, G->M.tid, n4) && get(pos, G->M.pos, n4) && get(end, G->d_end, n4) && get(flag, G->M.flag, n4) && get(mapq, G->M.mapq, n4) &&
+                  get(qlen, G->d_qlen, n4) && get(has_seq, G->M.l_seq, n4) && get(nm, G->M.nm, n4) && get(n_cigar, G->M.n_cigar, n4) &&
+                  get(pad.data(), G->M.pad_ops, (size_t)n * 8) && get(name_off.data(), G->d_name_off, (size_t)(n + 1) * 8) &&
+                  get(sa_off.data(), G->d_sa_off, (size_t)(n + 1) * 8) && get(names.data(), G->d_names, names.size()) &&
+                  get(sa_text.data(), G->d_sa_text, sa_text.size()) && get(&na_count, G->d_na_count, 4);
+        if (!ok || hipStreamSynchronize(stream) != hipSuccess) return fail(CORAL_ERR_HIP, std::string("copy of the batch's host fields failed: ") + hipGetErrorString(hipGetLastError()));
+        for (long long i = 0; i < n; ++i) {
+            has_seq[i] = has_seq[i] > 0 ? 1 : 0;                          // (arrived as l_seq)
+            D.cigar_off.push_back(D.cigar_off.back() + pad[(size_t)i]);
+        }
+        // read names -> ids (first appearance order), SA text -> rows
+        for (long long i = 0; i < n; ++i) {
+            const char *s = (const char *)names.data() + name_off[(size_t)i];
+            const size_t len = (size_t)(name_off[(size_t)i + 1] - name_off[(size_t)i]);
+            std::string nmstr(s, len ? strnlen(s, len - 1) : 0);          // as the CPU pipeline: the bytes in front of the last one, cut at a NUL
+            auto it = G->name_id.find(nmstr);
+            if (it == G->name_id.end()) {
+                it = G->name_id.emplace(nmstr, (int32_t)D.names.size()).first;
+                D.names.push_back(nmstr);
+            }
+            D.name_id.push_back(it->second);
+            int32_t cnt = 0;
+            if (sa_off[(size_t)i + 1] > sa_off[(size_t)i]) {
+                const char *q = (const char *)sa_text.data() + sa_off[(size_t)i];
+                const char *qe = q + (sa_off[(size_t)i + 1] - sa_off[(size_t)i]);
+                while (q < qe && *q) {
+                    const char *e = q;
+                    while (e < qe && *e && *e != ';') ++e;
+                    if (e > q) {
+                        int32_t row[8], snm = 0;
+                        if (!parse_sa_entry(q, e, G->ref_id, row, &snm)) return fail(CORAL_ERR_FORMAT, "malformed SA entry");
+                        D.sa.insert(D.sa.end(), row, row + 8);
+                        D.sa_nm.push_back(snm);
+                        ++cnt;
+                    }
+                    q = (e < qe && *e == ';') ? e + 1 : e;
+                }
+            }
+            D.sa_off.push_back(D.sa_off.back() + cnt);
+        }
+        // records with a non-ACGT code: fetched whole, their aligned non-ACGT positions come from the CPU pipeline's routine
+        if (na_count > 0) {
+            std::vector<int32_t> list((size_t)na_count);
+            std::vector<long long> starts((size_t)n);
+            if (hipMemcpy(list.data(), G->d_na_list, list.size() * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(starts.data(), G->d_rec_start, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess)
+                return fail(CORAL_ERR_HIP, "copy of the non-ACGT list failed");
+            std::sort(list.begin(), list.end());
+            std::vector<uint8_t> raw;
+            for (int32_t li : list) {
+                uint32_t bs = 0;
+                if (hipMemcpy(&bs, buf + starts[(size_t)li], 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(CORAL_ERR_HIP, "copy of a record failed");
+                raw.resize((size_t)bs);
+                if (hipMemcpy(raw.data(), buf + starts[(size_t)li] + 4, bs, hipMemcpyDeviceToHost) != hipSuccess) return fail(CORAL_ERR_HIP, "copy of a record failed");
+                Partial pt;
+                std::string err;
+                if (!decode_record(raw.data(), bs, G->ref_id, pt, err)) return fail(CORAL_ERR_FORMAT, err);
+                for (size_t j = 0; j < pt.na_pos.size(); ++j) {
+                    D.na_rec.push_back((int64_t)base + li);
+                    D.na_pos.push_back(pt.na_pos[j]);
+                }
+            }
+            G->na_records += na_count;
+        }
+    } else if (hipStreamSynchronize(stream) != hipSuccess) {
+        return fail(CORAL_ERR_HIP, "hipStreamSynchronize failed");
+    }
+    G->host_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_host0).count();
+    // this buffer may be inflated into again (batch k + 2) once everything above has run
+    if (hipEventRecord(G->ev_parsed[slot], stream) != hipSuccess) return fail(CORAL_ERR_HIP, "hipEventRecord failed");
+    G->have_cur = false;
+    ++G->k;
+    if (G->finished) D.seconds = G->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - G->t_start).count();
+    return CORAL_OK;
+}
+
+// The host-side half of the result as a handle for coral_bam_decode_sizes / coral_bam_decode_fill / coral_bam_decode_stats
+// (cigar: pass NULL to coral_bam_decode_fill — the ops are on the device).  Owned by the GPU decoder: do not close it.
+extern "C" int coral_bamgpu_host(void *handle, void **decoded) {
+    GpuDecoder *G = (GpuDecoder *)handle;
+    if (!G || !decoded) return CORAL_ERR_ARG;
+    *decoded = &G->D;
+    return CORAL_OK;
+}
+
+// stats: [0] batches, [1] segments whose speculative start was replaced by the exact walk, [2] records fetched for the
+// non-ACGT list, [3] batch capacity (inflated bytes); seconds: [0] total, [1] host-side field handling
+extern "C" int coral_bamgpu_stats(void *handle, int64_t stats[4], double seconds[2]) {
+    GpuDecoder *G = (GpuDecoder *)handle;
+    if (!G || !stats || !seconds) return CORAL_ERR_ARG;
+    stats[0] = G->n_batches; stats[1] = G->fixups; stats[2] = G->na_records; stats[3] = (int64_t)G->infl_cap;
+    seconds[0] = G->seconds; seconds[1] = G->host_seconds;
+    return CORAL_OK;
+}
+
+extern "C" int coral_bamgpu_close(void *handle) {
+    delete (GpuDecoder *)handle;
+    return CORAL_OK;
+}
+
+// One BGZF-style inflate launch on caller-provided buffers (tests; tools/bench_inflate.py): `desc` = n_blocks x 4 uint32
+// (src_off, src_len, dst_off, isize) on the device, `comp` readable COMP_SLACK bytes beyond its last stream.
+extern "C" int coral_bgzf_inflate(const uint8_t *comp, const uint32_t *desc, int32_t n_blocks, uint8_t *out, int32_t *status, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_blocks < 0 || (n_blocks > 0 && (!comp || !desc || !out || !status))) return CORAL_ERR_ARG;
+    if (n_blocks == 0) return CORAL_OK;
+    hipLaunchKernelGGL(k_bgzf_inflate, dim3((n_blocks + INFL_WAVES - 1) / INFL_WAVES), dim3(INFL_WAVES * WAVE), 0, stream, comp, (const BlockDesc *)desc,
+                       n_blocks, out, status);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("k_bgzf_inflate: ") + hipGetErrorString(e)); return CORAL_ERR_HIP; }
+    return CORAL_OK;
+}

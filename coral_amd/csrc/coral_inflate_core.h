@@ -1,0 +1,362 @@
+// coral_inflate_core.h — RFC 1951 (DEFLATE) decoder core of the GPU BGZF path (coral_bamgpu.hip).
+//
+// One 64-lane wave inflates one BGZF block (<= 64 KiB of output, one gzip member).  Symbol decoding is serial by nature and
+// runs as WAVE-UNIFORM code (every lane computes the same values; the table entry read from LDS is made scalar with
+// readfirstlane), the lanes do what is parallel: building the Huffman lookup tables (one table entry per lane and step),
+// holding the next 256 input bytes in a register (the bit buffer is refilled with v_readlane, never from memory), parking up
+// to 64 literals in a register until a full line can be stored, and copying LZ77 matches 64 bytes per step.
+//
+// The core is written against a small backend interface (`Wave`) so that the very same decode logic also compiles for the
+// host, where tests/test_inflate_core.py drives it against zlib on random, text-like, stored and fixed-Huffman streams (the
+// host backend runs "lanes" as loops).  The product only ever uses the device backend; nothing here is a CPU fallback.
+//
+// Replaces (with coral_bamgpu.hip) what the reference gets from pysam / htslib's bgzf_read + inflate when it opens
+// the BAM (/root/reference/src/infer_breakpoint_graph.py:65, :140).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define CORAL_HD __host__ __device__ __forceinline__
+#else
+#define CORAL_HD inline
+#endif
+
+namespace coral_inflate {
+
+enum { LL_BITS = 10, D_BITS = 8, WAVE_LANES = 64 };
+enum { OK = 0, ERR_BTYPE = 1, ERR_STORED = 2, ERR_CODELENS = 3, ERR_OVERSUBSCRIBED = 4, ERR_BAD_CODE = 5, ERR_DISTANCE = 6,
+       ERR_OVERFLOW = 7, ERR_INPUT = 8, ERR_SHORT = 9 };
+
+// Lookup-table entry (32 bits):  bits 0..3 code length (0 = not in the primary table: longer code or unused pattern),
+// bits 4..5 kind (litlen table: 0 literal, 1 length, 2 end of block), bits 8..11 extra bits, bits 16..31 base value.
+enum { KIND_LIT = 0, KIND_LEN = 1, KIND_EOB = 2 };
+CORAL_HD uint32_t make_entry(uint32_t nbits, uint32_t kind, uint32_t extra, uint32_t base) {
+    return nbits | (kind << 4) | (extra << 8) | (base << 16);
+}
+
+struct Tables {                      // per wave, in LDS on the device
+    uint32_t ll[1 << LL_BITS];       // literal / length codes of up to LL_BITS bits, indexed by the next LL_BITS stream bits
+    uint32_t dt[1 << D_BITS];        // distance codes of up to D_BITS bits
+    uint32_t ll_count[16], d_count[16];      // codes per length (canonical decode of the long codes; table build)
+    uint16_t ll_sym[288 + 32];       // symbols sorted by (length, symbol); [288..320) = the same for the distance code
+    uint8_t lens[320 + 4];           // code lengths while a dynamic header is read
+};
+
+// length symbol 257 + i -> (base, extra bits);  distance symbol d -> (base, extra bits)      (RFC 1951 §3.2.5, computed)
+CORAL_HD uint32_t ll_entry(uint32_t sym, uint32_t nbits) {
+    if (sym < 256) return make_entry(nbits, KIND_LIT, 0, sym);
+    if (sym == 256) return make_entry(nbits, KIND_EOB, 0, 0);
+    const uint32_t i = sym - 257;
+    if (i > 28) return 0;                                   // 286, 287: not valid in a stream
+    if (i < 8) return make_entry(nbits, KIND_LEN, 0, 3 + i);
+    if (i == 28) return make_entry(nbits, KIND_LEN, 0, 258);
+    const uint32_t e = (i >> 2) - 1;
+    return make_entry(nbits, KIND_LEN, e, 3 + ((4 + (i & 3)) << e));
+}
+CORAL_HD uint32_t dist_entry(uint32_t d, uint32_t nbits) {
+    if (d > 29) return 0;
+    if (d < 4) return make_entry(nbits, 0, 0, 1 + d);
+    const uint32_t e = (d >> 1) - 1;
+    return make_entry(nbits, 0, e, 1 + ((2 + (d & 1)) << e));
+}
+
+// Backend interface (`W`):
+//   int      lanes_begin() / per-lane execution: `for (int lane : W::lanes())` is spelled W_FOR_LANES(w, lane) below
+//   uint32_t uni(uint32_t)            make a value read from table memory wave-uniform (device: readfirstlane)
+//   uint32_t next_dword()             the next 32 input bits
+//   void     put_literal(uint32_t b)
+//   bool     copy_match(int len, int dist)     false: distance reaches in front of the output
+//   bool     copy_stored(long long dwords, uint32_t n)   n raw bytes, starting `dwords` dwords into the input window, to the output
+//   uint32_t reset_input_after_stored(long long dwords, uint32_t n)   restart the window behind those bytes; returns the bits
+//                                     to drop from the first dword of the new window (device windows are dword-aligned)
+//   bool     input_exhausted()        more input pulled than the stream holds (corrupt data)
+//   int      produced()               output bytes so far;   int capacity()
+//   void     add_count(uint32_t *c)   atomic / plain increment of a table counter
+//   void     fence()                  order table writes of all lanes before later reads
+// On the device W_FOR_LANES runs its body once with the wave's own lane id; on the host it loops over 64 lanes.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define W_FOR_LANES(w, lane) for (int lane = (w).lane, _once = 1; _once; _once = 0)
+#else
+#define W_FOR_LANES(w, lane) for (int lane = 0; lane < WAVE_LANES; ++lane)
+#endif
+
+template <class W>
+struct Inflater {
+    W &w;
+    Tables *T;
+    uint64_t bb = 0;          // bit buffer (LSB first), wave-uniform
+    int bc = 0;               // valid bits in it
+    long long dwords = 0;     // input dwords pulled into the bit buffer since the last reset_input
+
+    CORAL_HD Inflater(W &w_, Tables *t) : w(w_), T(t) {}
+
+    CORAL_HD void need() {                       // afterwards bc > 32
+        if (bc <= 32) {
+            bb |= (uint64_t)w.next_dword() << bc;
+            bc += 32;
+            ++dwords;
+        }
+    }
+    CORAL_HD uint32_t bits(int n) {              // n <= 32 and n <= bc
+        const uint32_t v = (uint32_t)(bb & ((1ull << n) - 1ull));
+        bb >>= n;
+        bc -= n;
+        return v;
+    }
+
+    // Canonical Huffman tables from code lengths lens[0 .. n): count[], sorted symbols, and the primary lookup table.
+    // Returns OK, or ERR_OVERSUBSCRIBED.  (Incomplete codes are accepted; their unused patterns decode to "bad code".)
+    CORAL_HD int build(const uint8_t *lens, int n, uint32_t *count, uint16_t *sym, uint32_t *table, int prim_bits, bool is_dist) {
+        W_FOR_LANES(w, lane) { if (lane < 16) count[lane] = 0; }
+        w.fence();
+        W_FOR_LANES(w, lane) { for (int s = lane; s < n; s += WAVE_LANES) w.add_count(&count[lens[s]]); }
+        w.fence();
+        int left = 1;
+        for (int l = 1; l <= 15; ++l) {
+            left <<= 1;
+            left -= (int)w.uni(count[l]);
+            if (left < 0) return ERR_OVERSUBSCRIBED;
+        }
+        // symbols of equal length in increasing symbol order: lane l places the symbols of length l
+        W_FOR_LANES(w, lane) {
+            if (lane >= 1 && lane <= 15) {
+                uint32_t at = 0;
+                for (int l = 1; l < lane; ++l) at += count[l];
+                for (int s = 0; s < n; ++s)
+                    if (lens[s] == lane) sym[at++] = (uint16_t)s;
+            }
+        }
+        w.fence();
+        // every table index is decoded canonically, bit by bit (entries are independent: one per lane and step)
+        const int size = 1 << prim_bits;
+        W_FOR_LANES(w, lane) {
+            for (int i = lane; i < size; i += WAVE_LANES) {
+                uint32_t code = 0, first = 0, index = 0, entry = 0;
+                for (int l = 1; l <= prim_bits; ++l) {
+                    code |= ((uint32_t)i >> (l - 1)) & 1u;
+                    const uint32_t cnt = count[l];
+                    if (code - first < cnt) {                     // (unsigned: code >= first always holds here)
+                        const uint32_t s = sym[index + (code - first)];
+                        entry = is_dist ? dist_entry(s, (uint32_t)l) : ll_entry(s, (uint32_t)l);
+                        break;
+                    }
+                    index += cnt;
+                    first = (first + cnt) << 1;
+                    code <<= 1;
+                }
+                table[i] = entry;
+            }
+        }
+        w.fence();
+        return OK;
+    }
+
+    // A code longer than the primary table (or an unused pattern): canonical decode from the first bit.  Returns the symbol
+    // or -1.  Needs up to 15 bits in the buffer (callers have > 32).
+    CORAL_HD int decode_long(const uint32_t *count, const uint16_t *sym) {
+        uint32_t code = 0, first = 0, index = 0;
+        for (int l = 1; l <= 15; ++l) {
+            code |= (uint32_t)(bb >> (l - 1)) & 1u;
+            const uint32_t cnt = w.uni(count[l]);
+            if (code - first < cnt) {
+                bb >>= l;
+                bc -= l;
+                return (int)w.uni(sym[index + (code - first)]);
+            }
+            index += cnt;
+            first = (first + cnt) << 1;
+            code <<= 1;
+        }
+        return -1;
+    }
+
+    CORAL_HD int read_dynamic_header() {
+        need();
+        const int hlit = (int)bits(5) + 257, hdist = (int)bits(5) + 1, hclen = (int)bits(4) + 4;
+        if (hlit > 286 || hdist > 30) return ERR_CODELENS;
+        uint8_t *lens = T->lens;
+        // code-length code: 19 symbols, 3 bits each, in the permuted order of RFC 1951 §3.2.7
+        W_FOR_LANES(w, lane) { if (lane < 19) lens[lane] = 0; }
+        w.fence();
+        for (int i = 0; i < hclen; ++i) {
+            need();
+            const uint32_t v = bits(3);
+            int pos;                                       // 16 17 18 0 | 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+            if (i < 3) pos = 16 + i;
+            else if (i == 3) pos = 0;
+            else {
+                const int k = i - 4;
+                pos = (k & 1) ? 7 - (k >> 1) : 8 + (k >> 1);
+            }
+            W_FOR_LANES(w, lane) { if (lane == 0) lens[pos] = (uint8_t)v; }
+        }
+        w.fence();
+        // the code-length code is decoded canonically (7-bit codes, at most 316 symbols): count / sym reuse the distance slots
+        uint32_t *cl_count = T->d_count;
+        uint16_t *cl_sym = T->ll_sym + 288;
+        {
+            W_FOR_LANES(w, lane) { if (lane < 16) cl_count[lane] = 0; }
+            w.fence();
+            W_FOR_LANES(w, lane) { if (lane < 19) w.add_count(&cl_count[lens[lane]]); }
+            w.fence();
+            int left = 1;
+            for (int l = 1; l <= 7; ++l) {
+                left <<= 1;
+                left -= (int)w.uni(cl_count[l]);
+                if (left < 0) return ERR_OVERSUBSCRIBED;
+            }
+            W_FOR_LANES(w, lane) {
+                if (lane >= 1 && lane <= 7) {
+                    uint32_t at = 0;
+                    for (int l = 1; l < lane; ++l) at += cl_count[l];
+                    for (int s = 0; s < 19; ++s)
+                        if (lens[s] == lane) cl_sym[at++] = (uint16_t)s;
+                }
+            }
+            w.fence();
+        }
+        // the hlit + hdist code lengths (they may run across the boundary between the two alphabets)
+        const int total = hlit + hdist;
+        // lens[] is reused as the output: the 19 code-length lengths are no longer needed once count / sym are built
+        int i = 0;
+        uint32_t prev = 0;
+        while (i < total) {
+            need();
+            const int s = decode_long(cl_count, cl_sym);
+            if (s < 0) return ERR_CODELENS;
+            if (s < 16) {
+                W_FOR_LANES(w, lane) { if (lane == 0) lens[i] = (uint8_t)s; }
+                prev = (uint32_t)s;
+                ++i;
+            } else {
+                uint32_t rep, val;
+                if (s == 16) {
+                    if (i == 0) return ERR_CODELENS;
+                    rep = 3 + bits(2);
+                    val = prev;
+                } else if (s == 17) {
+                    rep = 3 + bits(3);
+                    val = 0;
+                } else {
+                    rep = 11 + bits(7);
+                    val = 0;
+                }
+                if (i + (int)rep > total) return ERR_CODELENS;
+                W_FOR_LANES(w, lane) { for (int k = lane; k < (int)rep; k += WAVE_LANES) lens[i + k] = (uint8_t)val; }
+                prev = val;
+                i += (int)rep;
+            }
+        }
+        w.fence();
+        if (w.uni(lens[256]) == 0) return ERR_CODELENS;                 // no end-of-block code
+        int rc = build(lens, hlit, T->ll_count, T->ll_sym, T->ll, LL_BITS, false);
+        if (rc != OK) return rc;
+        return build(lens + hlit, hdist, T->d_count, T->ll_sym + 288, T->dt, D_BITS, true);
+    }
+
+    CORAL_HD int fixed_tables() {
+        uint8_t *lens = T->lens;
+        W_FOR_LANES(w, lane) {
+            for (int s = lane; s < 320; s += WAVE_LANES)
+                lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
+        }
+        w.fence();
+        int rc = build(lens, 288, T->ll_count, T->ll_sym, T->ll, LL_BITS, false);
+        if (rc != OK) return rc;
+        return build(lens + 288, 30, T->d_count, T->ll_sym + 288, T->dt, D_BITS, true);
+    }
+
+    // Stored block: LEN / NLEN after the next byte boundary, then LEN raw bytes.
+    CORAL_HD int stored() {
+        bits(bc & 7);                                   // to the byte boundary (bc stays a multiple of 8)
+        need();
+        const uint32_t len = bits(16), nlen = bits(16);
+        if ((len ^ 0xffffu) != nlen) return ERR_STORED;
+        if (w.produced() + (int)len > w.capacity()) return ERR_OVERFLOW;
+        // bytes still in the bit buffer belong to the block; the rest is copied straight from the input
+        uint32_t left = len;
+        while (left && bc >= 8) {
+            w.put_literal(bits(8));
+            --left;
+        }
+        if (left) {
+            // bit buffer is empty here: the input position is exactly `dwords` dwords into the window
+            if (!w.copy_stored(dwords, left)) return ERR_INPUT;
+            const uint32_t skip = w.reset_input_after_stored(dwords, left);      // bits to drop in the first dword of the new window
+            bb = 0;
+            bc = 0;
+            dwords = 0;
+            need();
+            bits((int)skip);
+        }
+        return OK;
+    }
+
+    CORAL_HD int codes() {
+        const uint32_t *ll = T->ll, *dt = T->dt;
+        for (;;) {
+            need();
+            uint32_t e = w.uni(ll[(uint32_t)bb & ((1u << LL_BITS) - 1u)]);
+            uint32_t nb = e & 15u;
+            if (nb == 0) {                                           // long code
+                const int s = decode_long(T->ll_count, T->ll_sym);
+                if (s < 0) return ERR_BAD_CODE;
+                e = ll_entry((uint32_t)s, 1);
+                if (e == 0) return ERR_BAD_CODE;
+            } else {
+                bb >>= nb;
+                bc -= (int)nb;
+            }
+            const uint32_t kind = (e >> 4) & 3u;
+            if (kind == KIND_LIT) {
+                if (w.produced() >= w.capacity()) return ERR_OVERFLOW;
+                w.put_literal(e >> 16);
+                continue;
+            }
+            if (kind == KIND_EOB) return OK;
+            const uint32_t xb = (e >> 8) & 15u;
+            const int len = (int)((e >> 16) + bits((int)xb));
+            need();
+            uint32_t d = w.uni(dt[(uint32_t)bb & ((1u << D_BITS) - 1u)]);
+            nb = d & 15u;
+            if (nb == 0) {
+                const int s = decode_long(T->d_count, T->ll_sym + 288);
+                if (s < 0) return ERR_BAD_CODE;
+                d = dist_entry((uint32_t)s, 1);
+                if (d == 0) return ERR_BAD_CODE;
+            } else {
+                bb >>= nb;
+                bc -= (int)nb;
+            }
+            const uint32_t dxb = (d >> 8) & 15u;
+            const int dist = (int)((d >> 16) + bits((int)dxb));
+            if (w.produced() + len > w.capacity()) return ERR_OVERFLOW;
+            if (!w.copy_match(len, dist)) return ERR_DISTANCE;
+            if (w.input_exhausted()) return ERR_INPUT;
+        }
+    }
+
+    // One raw DEFLATE stream (all its blocks).  `skip_bits`: bits of the window's first dword in front of the stream (device
+    // windows start on a dword boundary).  Returns OK when the final block ended and `capacity` bytes were produced.
+    CORAL_HD int run(int skip_bits = 0) {
+        if (skip_bits) {
+            need();
+            bits(skip_bits);
+        }
+        for (;;) {
+            need();
+            const uint32_t last = bits(1), type = bits(2);
+            int rc;
+            if (type == 0) rc = stored();
+            else if (type == 1) { rc = fixed_tables(); if (rc == OK) rc = codes(); }
+            else if (type == 2) { rc = read_dynamic_header(); if (rc == OK) rc = codes(); }
+            else rc = ERR_BTYPE;
+            if (rc != OK) return rc;
+            if (w.input_exhausted()) return ERR_INPUT;
+            if (last) break;
+        }
+        return w.produced() == w.capacity() ? OK : ERR_SHORT;
+    }
+};
+
+}  // namespace coral_inflate

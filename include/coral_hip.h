@@ -333,6 +333,40 @@ int coral_bam_write(const char *path, int64_t n_rec, const int32_t *tid, const i
                     const int32_t *ref_lens, uint32_t seed, int32_t level, int32_t n_threads);
 const char *coral_bam_last_error(void);
 
+/* ------------------------------------------------------------------------------------------------
+ * coral_bamgpu_* — the same decode with the inflate and the record parsing ON THE GPU: the host reads the file and sends
+ * COMPRESSED bytes over PCIe; BGZF blocks are inflated one per wave (k_bgzf_inflate), record boundaries found, CIGARs laid
+ * out in the padded SoA form of coral_records_t directly in HBM, and only a few hundred bytes per record (fixed fields,
+ * read name, SA text) come back for the host-side fields.  Same replacement as coral_bam_decode_*
+ * (/root/reference/src/infer_breakpoint_graph.py:65, :140-158), same results (tests/test_bam_gpu.py), same byte-range
+ * rule for rank / world.  The library allocates no device memory: the caller provides one workspace.
+ *
+ *   open   parse the header, size the batches (`batch_bytes` inflated bytes per batch; 0 = default 1 GiB, never more than
+ *          the byte range needs) -> *workspace_bytes the caller must allocate on the current device (256-byte aligned)
+ *   start  take the workspace, start reading / uploading / inflating
+ *   next   parse the next batch up to its sizes: out[0] records, out[1] padded CIGAR words, out[2] 1 = a batch is pending
+ *          (0 = the file is done), on `stream` (synchronises it)
+ *   emit   write the pending batch's CIGAR words to `cigar_dst` (device, out[1] words) and, if not NULL, its batch-local
+ *          op offsets to `cigar_off_dst` (device, out[0] + 1 int64); takes the batch's host-side fields in
+ *   host   the host-side half of the result as a handle for coral_bam_decode_sizes / _fill / _stats (cigar: pass NULL,
+ *          n_cigar_words is 0; cigar_off covers the whole decoded range); owned by the decoder, do not close it
+ *   stats  stats = batches, segments whose speculative record start was replaced by the exact walk, records fetched
+ *          whole for the non-ACGT list, batch capacity; seconds = total wall time, host-side field handling
+ * coral_bgzf_inflate: one inflate launch over caller-provided device buffers — desc = n_blocks x {src_off, src_len,
+ * dst_off, isize} uint32 (raw DEFLATE streams in `comp`, which must be readable 4096 bytes beyond the last stream);
+ * status[b] = 0 or the decoder's error code.
+ * ------------------------------------------------------------------------------------------------ */
+int coral_bamgpu_open(const char *path, int32_t n_threads, int32_t rank, int32_t world, int64_t batch_bytes, void **handle,
+                      int64_t *workspace_bytes);
+int coral_bamgpu_start(void *handle, void *workspace, int64_t workspace_bytes);
+int coral_bamgpu_next(void *handle, int64_t out[4], void *stream);
+int coral_bamgpu_emit(void *handle, uint32_t *cigar_dst, int64_t *cigar_off_dst, void *stream);
+int coral_bamgpu_host(void *handle, void **decoded);
+int coral_bamgpu_stats(void *handle, int64_t stats[4], double seconds[2]);
+int coral_bamgpu_close(void *handle);
+int coral_bgzf_inflate(const uint8_t *comp, const uint32_t *desc, int32_t n_blocks, uint8_t *out, int32_t *status,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif

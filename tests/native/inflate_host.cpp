@@ -1,0 +1,60 @@
+// Host build of the DEFLATE core of the GPU BGZF path (coral_amd/csrc/coral_inflate_core.h) for tests/test_inflate_core.py:
+// the decode logic (header parsing, canonical tables, symbol loop, stored / fixed blocks, error paths) is the code the device
+// runs; only the backend differs (lanes are loops, memory is plain arrays).  Test infrastructure, never part of libcoral_hip.so.
+#include <string.h>
+
+#include "../../coral_amd/csrc/coral_inflate_core.h"
+
+using namespace coral_inflate;
+
+struct HostWave {
+    const uint8_t *src;
+    long long src_len;
+    uint8_t *out;
+    int cap;
+    int o = 0;
+    long long win0 = 0;       // byte position of dword 0 of the current window
+    long long pulled = 0;     // dwords pulled from the current window
+    uint32_t uni(uint32_t x) const { return x; }
+    uint32_t next_dword() {
+        uint32_t v = 0;
+        const long long p = win0 + 4 * pulled;
+        for (int k = 0; k < 4; ++k)
+            if (p + k < src_len) v |= (uint32_t)src[p + k] << (8 * k);
+        ++pulled;
+        return v;
+    }
+    bool input_exhausted() const { return win0 + 4 * pulled > src_len + 8; }
+    void put_literal(uint32_t b) { out[o++] = (uint8_t)b; }
+    bool copy_match(int len, int dist) {
+        if (dist > o) return false;
+        for (int k = 0; k < len; ++k) out[o + k] = out[o + k - dist];
+        o += len;
+        return true;
+    }
+    bool copy_stored(long long dwords, uint32_t n) {
+        const long long from = win0 + 4 * dwords;
+        if (from + (long long)n > src_len) return false;
+        memcpy(out + o, src + from, n);
+        o += (int)n;
+        return true;
+    }
+    uint32_t reset_input_after_stored(long long dwords, uint32_t n) {
+        win0 = win0 + 4 * dwords + n;
+        pulled = 0;
+        return 0;
+    }
+    int produced() const { return o; }
+    int capacity() const { return cap; }
+    void add_count(uint32_t *c) { ++*c; }
+    void fence() {}
+};
+
+extern "C" int coral_test_inflate(const uint8_t *src, long long n, uint8_t *out, int cap, int *produced) {
+    static Tables T;
+    HostWave w{src, n, out, cap};
+    Inflater<HostWave> inf(w, &T);
+    const int rc = inf.run();
+    *produced = w.o;
+    return rc;
+}
