@@ -49,78 +49,173 @@ struct BlockDesc {
 // ---------------------------------------------------------------------------------------------
 // K_inflate
 // ---------------------------------------------------------------------------------------------
+#define RING_BYTES 1024                  // recent output per wave, in LDS: LZ77 matches read it instead of global memory
+#define RING_MASK (RING_BYTES - 1)
+
+// Output positions are counted in "aligned coordinates" A = (out & 255) + o, so that A = 0 is a 256-byte line of global memory:
+// ring index = A & RING_MASK, global address = gbase + A.  Literals are parked in a register (v_writelane into lane A & 63) and
+// written to the ring 64 at a time; matches copy ring -> ring (global -> ring when the source has left the ring); completed
+// 256-byte lines go to global memory as one dword store per lane.  Input: two registers of 64 dwords each, used alternately
+// (the bit buffer is refilled with v_readlane, never from memory).
 struct DevWave {
+    static constexpr bool paired_literals = true;       // coral_inflate_core.h: Inflater::codes_paired is the symbol loop
     int lane;
-    const uint32_t *words;      // dword-aligned start of the stream's window
-    const uint8_t *stream;      // first byte of the DEFLATE stream
+    const char *in_base;        // dword-aligned start of the stream's input window (global memory)
+    long long stream_off;       // first byte of the DEFLATE stream, relative to in_base (0..3)
     long long stream_len;
-    long long base_dw;          // dword index (from `words`) the Inflater's `dwords` counts from
-    long long win;              // dword index of lane 0 of `cur`
-    uint32_t cur, nxt;          // lane i: words[win + i], words[win + 64 + i]
-    int idx;                    // next lane of `cur`
+    long long base_dw;          // dword index (from in_base) the Inflater's `dwords` counts from
+    long long win;              // dword index of lane 0 of r0
+    long long last_dw;          // dword index of the stream's last byte
+    uint32_t r0, r1;            // lane i: dwords win + i and win + 64 + i of the input
+    int idx;                    // next dword of the 128 (0..63: r0, 64..127: r1)
     long long pulled;           // dwords handed out in total
-    uint8_t *out;
-    int cap, o, pfrom;
-    uint32_t pend, obase;
+    uint8_t *gbase;             // out - (out & 255)
+    uint8_t *ring;              // LDS, RING_BYTES
+    int cap;                    // output bytes of the block
+    int a0;                     // out & 255
+    int abase, slot;            // next output byte = abase + slot (aligned coordinates; abase a multiple of 64, slot 0..63)
+    int pfrom, gdone;           // first parked literal, first byte not yet in global memory
+    uint32_t pend;
+    bool over;                  // more output than the block may have (the excess is dropped)
 
     __device__ __forceinline__ uint32_t uni(uint32_t x) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+    // keeps the table-index arithmetic of the symbol loop on the vector pipe (the scalar pipe is the busy one)
+    __device__ __forceinline__ uint32_t vec(uint32_t x) const {
+        asm("" : "+v"(x));
+        return x;
+    }
+    // Input window loads never start behind the stream's last dword: a corrupt stream that keeps asking for input re-reads the
+    // end (and is reported by input_exhausted) instead of walking out of the compressed buffer (which is readable COMP_SLACK
+    // bytes beyond its last stream, more than one 256-byte window).
+    __device__ __forceinline__ uint32_t input_load(long long dw) const {
+        const long long d = dw < last_dw ? dw : last_dw;
+        return *reinterpret_cast<const uint32_t *>(in_base + d * 4 + lane * 4);
+    }
     __device__ __forceinline__ void load_window() {
-        cur = words[win + lane];
-        nxt = words[win + WAVE + lane];
+        r0 = input_load(win);
+        r1 = input_load(win + WAVE);
         idx = 0;
     }
     __device__ __forceinline__ uint32_t next_dword() {
-        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)cur, idx);
-        ++idx;
+        uint32_t v;
         ++pulled;
-        if (idx == WAVE) {
-            cur = nxt;
-            win += WAVE;
-            nxt = words[win + WAVE + lane];
-            idx = 0;
+        if (idx < WAVE) {
+            v = (uint32_t)__builtin_amdgcn_readlane((int)r0, idx);
+            if (++idx == WAVE) r0 = input_load(win + 2 * WAVE);     // r0 is used up: refill it for the turn after r1's
+        } else {
+            v = (uint32_t)__builtin_amdgcn_readlane((int)r1, idx - WAVE);
+            if (++idx == 2 * WAVE) {                                // r1 is used up
+                win += 2 * WAVE;
+                r1 = input_load(win + WAVE);
+                idx = 0;
+            }
         }
         return v;
     }
     __device__ __forceinline__ bool input_exhausted() const { return pulled * 4 > stream_len + 16; }
+    __device__ __forceinline__ int pos() const { return abase + slot; }
+    __device__ __forceinline__ void set_pos(int a) {
+        abase = a & ~63;
+        slot = a & 63;
+    }
+    // parked literals -> ring
     __device__ __forceinline__ void flush() {
-        if (pfrom < o) {
-            const int wb = (int)((obase + (uint32_t)pfrom) & ~63u) - (int)obase;
-            const int p = wb + lane;
-            if (p >= pfrom && p < o) out[p] = (uint8_t)pend;
-            pfrom = o;
+        const int a = pos();
+        if (pfrom < a) {
+            const int p = (pfrom & ~63) + lane;                        // the parked bytes lie inside one 64-byte window
+            if (p >= pfrom && p < a) ring[p & RING_MASK] = (uint8_t)pend;
+            pfrom = a;
         }
     }
+    // completed 256-byte lines ring -> global memory (the block's first line may start inside a line: byte stores there)
+    __device__ __forceinline__ void drain() {
+        const int a = pos();
+        if (a - gdone < 256) return;
+        if (gdone & 255) {
+            const int upto = (gdone | 255) + 1;
+#pragma nounroll
+            for (int p = gdone + lane; p < upto; p += WAVE) gbase[p] = ring[p & RING_MASK];
+            gdone = upto;
+        }
+#pragma nounroll
+        while (a - gdone >= 256) {
+            const int p = gdone + 4 * lane;
+            *reinterpret_cast<uint32_t *>(gbase + p) = *reinterpret_cast<const uint32_t *>(ring + (p & RING_MASK));
+            gdone += 256;
+        }
+    }
+    __device__ __forceinline__ void clamp() {                         // never hand more than `cap` bytes to flush / drain
+        if (pos() - a0 > cap) {
+            over = true;
+            set_pos(a0 + cap);
+            if (pfrom > a0 + cap) pfrom = a0 + cap;
+        }
+    }
+    __device__ __forceinline__ void finish() {                        // everything left goes out byte by byte
+        clamp();
+        flush();
+        const int a = pos();
+#pragma nounroll
+        for (int p = gdone + lane; p < a; p += WAVE) gbase[p] = ring[p & RING_MASK];
+        gdone = a;
+    }
+    __device__ __forceinline__ void window_full() {                   // slot == 64
+        abase += 64;
+        slot = 0;
+        clamp();
+        flush();
+        drain();
+    }
+    // `b`: the byte, as a per-lane or a uniform value (the hot loop passes the table entry's byte straight from the vector
+    // register it was loaded into: extract, compare, select — three vector instructions and no scalar one)
     __device__ __forceinline__ void put_literal(uint32_t b) {
-        const int l = (int)((obase + (uint32_t)o) & 63u);
-        pend = lane == l ? b : pend;
-        ++o;
-        if (((obase + (uint32_t)o) & 63u) == 0u) flush();
+        pend = lane == slot ? b : pend;
+        if (++slot == 64) window_full();
     }
     __device__ __forceinline__ bool copy_match(int len, int dist) {
-        if (dist > o) return false;
+        const int a = pos();
+        if (dist > a - a0) return false;
         flush();
-        uint8_t *dstp = out + o;
-        const uint8_t *srcp = dstp - dist;
-        if (dist >= len) {                                   // source and destination do not overlap
-            for (int k = lane; k < len; k += WAVE) dstp[k] = srcp[k];
-        } else {                                             // a pattern of period `dist`: byte k = pattern[k mod dist]
-            const uint32_t m = ((1u << 20) + (uint32_t)dist - 1u) / (uint32_t)dist;      // exact for k < 258 (error < 258 / 2^20 < 1 / dist)
-            for (int k = lane; k < len; k += WAVE) {
-                const uint32_t q = ((uint32_t)k * m) >> 20;
-                dstp[k] = srcp[k - (int)(q * (uint32_t)dist)];
+        if (dist <= RING_BYTES - 64) {
+            if (dist >= WAVE || dist >= len) {
+                // chunks of 64 bytes in order: a chunk's sources were written by earlier chunks at the latest (LDS is in order)
+#pragma nounroll
+                for (int k = lane; k < len; k += WAVE) ring[(a + k) & RING_MASK] = ring[(a + k - dist) & RING_MASK];
+            } else {                                             // a pattern of period `dist` < 64: byte k = pattern[k mod dist]
+                const uint32_t m = ((1u << 20) + (uint32_t)dist - 1u) / (uint32_t)dist;      // exact for k < 258 (error < 258 / 2^20 < 1 / dist)
+#pragma nounroll
+                for (int k = lane; k < len; k += WAVE) {
+                    const uint32_t q = ((uint32_t)k * m) >> 20;
+                    ring[(a + k) & RING_MASK] = ring[(a - dist + k - (int)(q * (uint32_t)dist)) & RING_MASK];
+                }
             }
+        } else {
+            // the source left the ring: it is in global memory (drained up to a - 255 at least; a - dist + len lies below that)
+            const uint8_t *src = gbase + (a - dist);
+#pragma nounroll
+            for (int k = lane; k < len; k += WAVE) ring[(a + k) & RING_MASK] = src[k];
         }
-        o += len;
-        pfrom = o;
+        set_pos(a + len);
+        pfrom = a + len;
+        drain();
         return true;
     }
     __device__ __forceinline__ bool copy_stored(long long dwords, uint32_t n) {
-        const long long from = 4 * (base_dw + dwords) - (long long)(stream - (const uint8_t *)words);     // relative to the stream
+        const long long from = 4 * (base_dw + dwords) - stream_off;       // relative to the stream
         if (from < 0 || from + (long long)n > stream_len) return false;
         flush();
-        for (uint32_t k = (uint32_t)lane; k < n; k += WAVE) out[o + (int)k] = stream[from + k];
-        o += (int)n;
-        pfrom = o;
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(in_base) + stream_off + from;
+#pragma nounroll
+        for (uint32_t done = 0; done < n;) {                      // through the ring, 256 bytes at a time (it is drained in step)
+            const uint32_t step = n - done < 256u ? n - done : 256u;
+            const int a = pos();
+#pragma nounroll
+            for (uint32_t k = (uint32_t)lane; k < step; k += WAVE) ring[(a + (int)k) & RING_MASK] = src[done + k];
+            set_pos(a + (int)step);
+            pfrom = a + (int)step;
+            drain();
+            done += step;
+        }
         return true;
     }
     __device__ __forceinline__ uint32_t reset_input_after_stored(long long dwords, uint32_t n) {
@@ -130,7 +225,7 @@ struct DevWave {
         load_window();
         return (uint32_t)(byte & 3) * 8u;
     }
-    __device__ __forceinline__ int produced() const { return o; }
+    __device__ __forceinline__ int produced() const { return pos() - a0; }
     __device__ __forceinline__ int capacity() const { return cap; }
     __device__ __forceinline__ void add_count(uint32_t *c) { atomicAdd(c, 1u); }
     __device__ __forceinline__ void fence() {
@@ -143,6 +238,7 @@ struct DevWave {
 __global__ __launch_bounds__(INFL_WAVES *WAVE) void k_bgzf_inflate(const uint8_t *__restrict__ comp, const BlockDesc *__restrict__ desc,
                                                                      int n_blocks, uint8_t *out, int32_t *__restrict__ status) {
     __shared__ coral_inflate::Tables tables[INFL_WAVES];
+    __shared__ __attribute__((aligned(16))) uint8_t rings[INFL_WAVES][RING_BYTES];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int b = blockIdx.x * INFL_WAVES + wib;
@@ -152,26 +248,31 @@ __global__ __launch_bounds__(INFL_WAVES *WAVE) void k_bgzf_inflate(const uint8_t
         if (lane == 0) status[b] = 0;
         return;
     }
-    const uint8_t *stream = comp + d.src_off;
-    const uintptr_t a = (uintptr_t)stream;
+    // (comp and out are 4- resp. 1-byte aligned allocations of the caller; pointers keep their kernel-argument provenance so
+    // that the loads and stores are global_*, not flat_*)
+    const uint32_t mis = (uint32_t)(((uintptr_t)comp + d.src_off) & 3u);
     DevWave w;
     w.lane = lane;
-    w.words = (const uint32_t *)(a & ~(uintptr_t)3);
-    w.stream = stream;
+    w.in_base = reinterpret_cast<const char *>(comp) + (d.src_off - mis);
+    w.stream_off = mis;
     w.stream_len = d.src_len;
     w.base_dw = 0;
     w.win = 0;
+    w.last_dw = ((long long)mis + d.src_len) >> 2;
     w.pulled = 0;
-    w.out = out + d.dst_off;
+    w.a0 = (int)(((uintptr_t)out + d.dst_off) & 255u);
+    w.gbase = out + ((long long)d.dst_off - w.a0);
+    w.ring = rings[wib];
     w.cap = (int)d.isize;
-    w.o = 0;
-    w.pfrom = 0;
+    w.set_pos(w.a0);
+    w.pfrom = w.gdone = w.a0;
     w.pend = 0;
-    w.obase = (uint32_t)((uintptr_t)w.out & 63u);
+    w.r0 = w.r1 = 0;
+    w.over = false;
     w.load_window();
     coral_inflate::Inflater<DevWave> inf(w, &tables[wib]);
-    const int rc = inf.run((int)(a & 3) * 8);
-    w.flush();
+    const int rc = inf.run((int)mis * 8);
+    w.finish();
     if (lane == 0) status[b] = rc;
 }
 

@@ -17,8 +17,10 @@
 
 #if defined(__HIPCC__)
 #define CORAL_HD __host__ __device__ __forceinline__
+#define CORAL_NOUNROLL _Pragma("nounroll")
 #else
 #define CORAL_HD inline
+#define CORAL_NOUNROLL
 #endif
 
 namespace coral_inflate {
@@ -27,15 +29,17 @@ enum { LL_BITS = 10, D_BITS = 8, WAVE_LANES = 64 };
 enum { OK = 0, ERR_BTYPE = 1, ERR_STORED = 2, ERR_CODELENS = 3, ERR_OVERSUBSCRIBED = 4, ERR_BAD_CODE = 5, ERR_DISTANCE = 6,
        ERR_OVERFLOW = 7, ERR_INPUT = 8, ERR_SHORT = 9 };
 
-// Lookup-table entry (32 bits):  bits 0..3 code length (0 = not in the primary table: longer code or unused pattern),
-// bits 4..5 kind (litlen table: 0 literal, 1 length, 2 end of block), bits 8..11 extra bits, bits 16..31 base value.
-enum { KIND_LIT = 0, KIND_LEN = 1, KIND_EOB = 2 };
+// Literal / length table entry (16 bits):  bits 0..3 code length (0 = not in the primary table: a longer code or an unused
+// pattern), bit 4 = "not a literal", bits 5..7 extra bits of a length code (7 = end of block), bits 8..15 the literal byte or
+// (length base - 3).  A literal is recognised by ONE bit test; a long / unused pattern is 0x0010.
+// Distance table entry (32 bits):  bits 0..3 code length (0 as above), bits 8..11 extra bits, bits 16..31 distance base.
+enum { LL_NOT_LITERAL = 16, LL_EOB_EXTRA = 7, LL_LONG = 0x0010 };
 CORAL_HD uint32_t make_entry(uint32_t nbits, uint32_t kind, uint32_t extra, uint32_t base) {
     return nbits | (kind << 4) | (extra << 8) | (base << 16);
 }
 
 struct Tables {                      // per wave, in LDS on the device
-    uint32_t ll[1 << LL_BITS];       // literal / length codes of up to LL_BITS bits, indexed by the next LL_BITS stream bits
+    uint16_t ll[1 << LL_BITS];       // literal / length codes of up to LL_BITS bits, indexed by the next LL_BITS stream bits
     uint32_t dt[1 << D_BITS];        // distance codes of up to D_BITS bits
     uint32_t ll_count[16], d_count[16];      // codes per length (canonical decode of the long codes; table build)
     uint16_t ll_sym[288 + 32];       // symbols sorted by (length, symbol); [288..320) = the same for the distance code
@@ -44,14 +48,14 @@ struct Tables {                      // per wave, in LDS on the device
 
 // length symbol 257 + i -> (base, extra bits);  distance symbol d -> (base, extra bits)      (RFC 1951 §3.2.5, computed)
 CORAL_HD uint32_t ll_entry(uint32_t sym, uint32_t nbits) {
-    if (sym < 256) return make_entry(nbits, KIND_LIT, 0, sym);
-    if (sym == 256) return make_entry(nbits, KIND_EOB, 0, 0);
+    if (sym < 256) return nbits | (sym << 8);
+    if (sym == 256) return nbits | LL_NOT_LITERAL | (LL_EOB_EXTRA << 5);
     const uint32_t i = sym - 257;
-    if (i > 28) return 0;                                   // 286, 287: not valid in a stream
-    if (i < 8) return make_entry(nbits, KIND_LEN, 0, 3 + i);
-    if (i == 28) return make_entry(nbits, KIND_LEN, 0, 258);
+    if (i > 28) return LL_LONG;                             // 286, 287: not valid in a stream (decoded as a bad code)
+    if (i < 8) return nbits | LL_NOT_LITERAL | (i << 8);
+    if (i == 28) return nbits | LL_NOT_LITERAL | (255u << 8);
     const uint32_t e = (i >> 2) - 1;
-    return make_entry(nbits, KIND_LEN, e, 3 + ((4 + (i & 3)) << e));
+    return nbits | LL_NOT_LITERAL | (e << 5) | (((4 + (i & 3)) << e) << 8);
 }
 CORAL_HD uint32_t dist_entry(uint32_t d, uint32_t nbits) {
     if (d > 29) return 0;
@@ -106,12 +110,14 @@ struct Inflater {
 
     // Canonical Huffman tables from code lengths lens[0 .. n): count[], sorted symbols, and the primary lookup table.
     // Returns OK, or ERR_OVERSUBSCRIBED.  (Incomplete codes are accepted; their unused patterns decode to "bad code".)
-    CORAL_HD int build(const uint8_t *lens, int n, uint32_t *count, uint16_t *sym, uint32_t *table, int prim_bits, bool is_dist) {
+    CORAL_HD int build(const uint8_t *lens, int n, uint32_t *count, uint16_t *sym, uint16_t *table16, uint32_t *table32, int prim_bits) {
+        const bool is_dist = table32 != nullptr;
         W_FOR_LANES(w, lane) { if (lane < 16) count[lane] = 0; }
         w.fence();
         W_FOR_LANES(w, lane) { for (int s = lane; s < n; s += WAVE_LANES) w.add_count(&count[lens[s]]); }
         w.fence();
         int left = 1;
+        CORAL_NOUNROLL
         for (int l = 1; l <= 15; ++l) {
             left <<= 1;
             left -= (int)w.uni(count[l]);
@@ -121,7 +127,9 @@ struct Inflater {
         W_FOR_LANES(w, lane) {
             if (lane >= 1 && lane <= 15) {
                 uint32_t at = 0;
+                CORAL_NOUNROLL
                 for (int l = 1; l < lane; ++l) at += count[l];
+                CORAL_NOUNROLL
                 for (int s = 0; s < n; ++s)
                     if (lens[s] == lane) sym[at++] = (uint16_t)s;
             }
@@ -131,7 +139,8 @@ struct Inflater {
         const int size = 1 << prim_bits;
         W_FOR_LANES(w, lane) {
             for (int i = lane; i < size; i += WAVE_LANES) {
-                uint32_t code = 0, first = 0, index = 0, entry = 0;
+                uint32_t code = 0, first = 0, index = 0, entry = is_dist ? 0u : (uint32_t)LL_LONG;
+                CORAL_NOUNROLL
                 for (int l = 1; l <= prim_bits; ++l) {
                     code |= ((uint32_t)i >> (l - 1)) & 1u;
                     const uint32_t cnt = count[l];
@@ -144,7 +153,8 @@ struct Inflater {
                     first = (first + cnt) << 1;
                     code <<= 1;
                 }
-                table[i] = entry;
+                if (is_dist) table32[i] = entry;
+                else table16[i] = (uint16_t)entry;
             }
         }
         w.fence();
@@ -155,6 +165,7 @@ struct Inflater {
     // or -1.  Needs up to 15 bits in the buffer (callers have > 32).
     CORAL_HD int decode_long(const uint32_t *count, const uint16_t *sym) {
         uint32_t code = 0, first = 0, index = 0;
+        CORAL_NOUNROLL
         for (int l = 1; l <= 15; ++l) {
             code |= (uint32_t)(bb >> (l - 1)) & 1u;
             const uint32_t cnt = w.uni(count[l]);
@@ -170,7 +181,7 @@ struct Inflater {
         return -1;
     }
 
-    CORAL_HD int read_dynamic_header() {
+    CORAL_HD int read_dynamic_header(int *n_ll, int *n_dist) {
         need();
         const int hlit = (int)bits(5) + 257, hdist = (int)bits(5) + 1, hclen = (int)bits(4) + 4;
         if (hlit > 286 || hdist > 30) return ERR_CODELENS;
@@ -249,9 +260,9 @@ struct Inflater {
         }
         w.fence();
         if (w.uni(lens[256]) == 0) return ERR_CODELENS;                 // no end-of-block code
-        int rc = build(lens, hlit, T->ll_count, T->ll_sym, T->ll, LL_BITS, false);
-        if (rc != OK) return rc;
-        return build(lens + hlit, hdist, T->d_count, T->ll_sym + 288, T->dt, D_BITS, true);
+        *n_ll = hlit;
+        *n_dist = hdist;
+        return OK;
     }
 
     CORAL_HD int fixed_tables() {
@@ -261,9 +272,7 @@ struct Inflater {
                 lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
         }
         w.fence();
-        int rc = build(lens, 288, T->ll_count, T->ll_sym, T->ll, LL_BITS, false);
-        if (rc != OK) return rc;
-        return build(lens + 288, 30, T->d_count, T->ll_sym + 288, T->dt, D_BITS, true);
+        return OK;
     }
 
     // Stored block: LEN / NLEN after the next byte boundary, then LEN raw bytes.
@@ -292,8 +301,82 @@ struct Inflater {
         return OK;
     }
 
+    // The symbol loop the device uses (W::paired_literals), scheduled for the scalar pipe of a CU: a literal is ONE bit test on
+    // a 16-bit table entry; after a refill check (more than 32 bits) two table symbols are decoded back to back; the output
+    // capacity is not tested per literal — the backend drops excess output (clamp) and raises `over`, which is looked at
+    // once per pair.  The rare paths (codes longer than the table, bad codes) are loops, so the hot loop stays small.
+    // Needs from the backend, in addition: vec(x) (identity; keeps index arithmetic on the vector pipe), `over`, clamp().
+    CORAL_HD int codes_paired() {
+        const uint16_t *ll = T->ll;
+        const uint32_t *dt = T->dt;
+        uint32_t ev = 0;                                              // the entry as loaded (a vector register on the device)
+        for (;;) {
+            need();                                                   // more than 32 bits
+            ev = ll[w.vec((uint32_t)bb) & ((1u << LL_BITS) - 1u)];
+            uint32_t e = w.uni(ev);
+            if (!(e & LL_NOT_LITERAL)) {
+                const uint32_t nb1 = e & 15u;
+                bb >>= nb1;
+                bc -= (int)nb1;
+                w.put_literal(ev >> 8);
+                ev = ll[w.vec((uint32_t)bb) & ((1u << LL_BITS) - 1u)];     // at least 23 bits left: enough for any table entry
+                e = w.uni(ev);
+                if (!(e & LL_NOT_LITERAL)) {
+                    const uint32_t nb2 = e & 15u;
+                    bb >>= nb2;
+                    bc -= (int)nb2;
+                    w.put_literal(ev >> 8);
+                    if (w.over) return ERR_OVERFLOW;
+                    continue;
+                }
+            }
+            // a length, the end of the block, or a code that is not in the table (at least 23 bits in the buffer)
+            uint32_t nb = e & 15u;
+            if (nb == 0) {
+                const int s = decode_long(T->ll_count, T->ll_sym);    // up to 15 bits
+                if (s < 0) return ERR_BAD_CODE;
+                e = ll_entry((uint32_t)s, 1);
+                if (e == LL_LONG) return ERR_BAD_CODE;
+                if (!(e & LL_NOT_LITERAL)) {
+                    w.put_literal(e >> 8);
+                    if (w.over) return ERR_OVERFLOW;
+                    continue;
+                }
+            } else {
+                bb >>= nb;
+                bc -= (int)nb;
+            }
+            const uint32_t xb = (e >> 5) & 7u;
+            if (xb == LL_EOB_EXTRA) {
+                w.clamp();
+                return w.over ? ERR_OVERFLOW : OK;
+            }
+            const int len = (int)(3u + (e >> 8) + bits((int)xb));      // up to 5 more bits: 15 + 5 <= 23
+            need();
+            uint32_t d = w.uni(dt[(uint32_t)bb & ((1u << D_BITS) - 1u)]);
+            nb = d & 15u;
+            if (nb == 0) {
+                const int s = decode_long(T->d_count, T->ll_sym + 288);
+                if (s < 0) return ERR_BAD_CODE;
+                d = dist_entry((uint32_t)s, 1);
+                if (d == 0) return ERR_BAD_CODE;
+            } else {
+                bb >>= nb;
+                bc -= (int)nb;
+            }
+            const uint32_t dxb = (d >> 8) & 15u;
+            const int dist = (int)((d >> 16) + bits((int)dxb));       // 15 + 13 <= 32
+            if (w.over || w.produced() + len > w.capacity()) return ERR_OVERFLOW;
+            if (!w.copy_match(len, dist)) return ERR_DISTANCE;
+            if (w.input_exhausted()) return ERR_INPUT;
+        }
+    }
+
+    // The plain symbol loop (one symbol per round, capacity tested per literal).
     CORAL_HD int codes() {
-        const uint32_t *ll = T->ll, *dt = T->dt;
+        if constexpr (W::paired_literals) return codes_paired();
+        const uint16_t *ll = T->ll;
+        const uint32_t *dt = T->dt;
         for (;;) {
             need();
             uint32_t e = w.uni(ll[(uint32_t)bb & ((1u << LL_BITS) - 1u)]);
@@ -302,20 +385,19 @@ struct Inflater {
                 const int s = decode_long(T->ll_count, T->ll_sym);
                 if (s < 0) return ERR_BAD_CODE;
                 e = ll_entry((uint32_t)s, 1);
-                if (e == 0) return ERR_BAD_CODE;
+                if (e == LL_LONG) return ERR_BAD_CODE;
             } else {
                 bb >>= nb;
                 bc -= (int)nb;
             }
-            const uint32_t kind = (e >> 4) & 3u;
-            if (kind == KIND_LIT) {
+            if (!(e & LL_NOT_LITERAL)) {
                 if (w.produced() >= w.capacity()) return ERR_OVERFLOW;
-                w.put_literal(e >> 16);
+                w.put_literal(e >> 8);
                 continue;
             }
-            if (kind == KIND_EOB) return OK;
-            const uint32_t xb = (e >> 8) & 15u;
-            const int len = (int)((e >> 16) + bits((int)xb));
+            const uint32_t xb = (e >> 5) & 7u;
+            if (xb == LL_EOB_EXTRA) return OK;
+            const int len = (int)(3u + (e >> 8) + bits((int)xb));
             need();
             uint32_t d = w.uni(dt[(uint32_t)bb & ((1u << D_BITS) - 1u)]);
             nb = d & 15u;
@@ -347,10 +429,17 @@ struct Inflater {
             need();
             const uint32_t last = bits(1), type = bits(2);
             int rc;
-            if (type == 0) rc = stored();
-            else if (type == 1) { rc = fixed_tables(); if (rc == OK) rc = codes(); }
-            else if (type == 2) { rc = read_dynamic_header(); if (rc == OK) rc = codes(); }
-            else rc = ERR_BTYPE;
+            if (type == 0) {
+                rc = stored();
+            } else if (type == 3) {
+                rc = ERR_BTYPE;
+            } else {                                        // one build site and one decode loop for both Huffman block types
+                int n_ll = 288, n_dist = 30;
+                rc = type == 1 ? fixed_tables() : read_dynamic_header(&n_ll, &n_dist);
+                if (rc == OK) rc = build(T->lens, n_ll, T->ll_count, T->ll_sym, T->ll, nullptr, LL_BITS);
+                if (rc == OK) rc = build(T->lens + n_ll, n_dist, T->d_count, T->ll_sym + 288, nullptr, T->dt, D_BITS);
+                if (rc == OK) rc = codes();
+            }
             if (rc != OK) return rc;
             if (w.input_exhausted()) return ERR_INPUT;
             if (last) break;

@@ -7,7 +7,9 @@
 
 using namespace coral_inflate;
 
-struct HostWave {
+template <bool PAIRED>
+struct HostWaveT {
+    static constexpr bool paired_literals = PAIRED;
     const uint8_t *src;
     long long src_len;
     uint8_t *out;
@@ -25,7 +27,14 @@ struct HostWave {
         return v;
     }
     bool input_exhausted() const { return win0 + 4 * pulled > src_len + 8; }
-    void put_literal(uint32_t b) { out[o++] = (uint8_t)b; }
+    // paired loop: output beyond the capacity is dropped and flagged, as the device backend does (its ring absorbs it)
+    bool over = false;
+    uint32_t vec(uint32_t x) const { return x; }
+    void clamp() {}
+    void put_literal(uint32_t b) {
+        if (o >= cap) { over = true; return; }
+        out[o++] = (uint8_t)b;
+    }
     bool copy_match(int len, int dist) {
         if (dist > o) return false;
         for (int k = 0; k < len; ++k) out[o + k] = out[o + k - dist];
@@ -50,11 +59,18 @@ struct HostWave {
     void fence() {}
 };
 
-extern "C" int coral_test_inflate(const uint8_t *src, long long n, uint8_t *out, int cap, int *produced) {
+template <bool PAIRED>
+static int run(const uint8_t *src, long long n, uint8_t *out, int cap, int *produced) {
     static Tables T;
-    HostWave w{src, n, out, cap};
-    Inflater<HostWave> inf(w, &T);
+    HostWaveT<PAIRED> w;
+    w.src = src; w.src_len = n; w.out = out; w.cap = cap;
+    Inflater<HostWaveT<PAIRED>> inf(w, &T);
     const int rc = inf.run();
     *produced = w.o;
     return rc;
+}
+
+// paired = 1: the symbol loop the device runs (Inflater::codes_paired); 0: the plain loop
+extern "C" int coral_test_inflate(const uint8_t *src, long long n, uint8_t *out, int cap, int *produced, int paired) {
+    return paired ? run<true>(src, n, out, cap, produced) : run<false>(src, n, out, cap, produced);
 }

@@ -1,11 +1,12 @@
 """rocprofv3 --kernel-trace --stats output -> the markdown summary committed under profiles/ (libcoral_hip kernels only)."""
 import csv, glob, sys
 d, out_md, out_csv, cmd = sys.argv[1:5]
+note = sys.argv[5] if len(sys.argv) > 5 else "config 3: 2,000,000 reads x 20 kb, 2,163,774 records, 3.99e9 CIGAR ops = 16.04 GB algorithmic bytes per scan launch"
 f = glob.glob(d + "/**/*_kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 ours = [r for r in rows if any(t in r["Name"] for t in ("k_cigar_scan", "k_seg_", "k_point_cover", "k_bp_pairs", "k_group_", "k_hash_", "k_count_valid",
                                                        "k_first_primary", "k_heads", "k_iota", "k_order_counts", "k_read_length", "k_row_keys",
-                                                       "k_scatter", "k_all"))]
+                                                       "k_scatter", "k_all", "k_bgzf_", "k_bam_"))]
 total = sum(float(r["TotalDurationNs"]) for r in rows) / 1e6
 with open(out_csv, "w") as fp:
     w = csv.DictWriter(fp, fieldnames=list(rows[0].keys()))
@@ -14,11 +15,11 @@ with open(out_csv, "w") as fp:
         w.writerow(r)
 with open(out_md, "w") as fp:
     fp.write("# rocprofv3 --kernel-trace --stats (round 2)\n\nCommand: `%s`\n" % cmd)
-    fp.write("(config 3: 2,000,000 reads x 20 kb, 2,163,774 records, 3.99e9 CIGAR ops = 16.04 GB algorithmic bytes per scan launch).\n\n")
+    fp.write("(%s).\n\n" % note)
     fp.write("The run also contains the synthetic-data generator and hipcub/rocprim sorts: %d kernel rows, %.1f ms in total.\n" % (len(rows), total))
     fp.write("Kernels of libcoral_hip.so:\n\n| kernel | calls | total ms | avg ms | min ms | max ms |\n|---|---|---|---|---|---|\n")
     for r in sorted(ours, key=lambda r: -float(r["TotalDurationNs"])):
-        fp.write("| `%s` | %s | %.3f | %.3f | %.3f | %.3f |\n" % (r["Name"].split("(")[0].replace("void ", ""), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+        fp.write("| `%s` | %s | %.3f | %.3f | %.3f | %.3f |\n" % (r["Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", ""), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                               float(r["AverageNs"]) / 1e6, float(r["MinNs"]) / 1e6, float(r["MaxNs"]) / 1e6))
     scan = [r for r in ours if "k_cigar_scan" in r["Name"]]
     if scan:
