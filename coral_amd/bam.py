@@ -137,15 +137,18 @@ def decode_bam_gpu(path: str, device="cuda:0", n_threads: Optional[int] = None, 
         cigar = torch.cat(pieces) if len(pieces) > 1 else (pieces[0] if pieces else torch.zeros(0, dtype=torch.int32, device=dev))
         del pieces
         dh = C.c_void_p()
-        _lib.check(L.coral_bamgpu_host(h, C.byref(dh)), "coral_bamgpu_host")
+        rc = L.coral_bamgpu_host(h, C.byref(dh))
+        if rc != 0:
+            raise fail("coral_bamgpu_host", rc)
         st, secs = (C.c_int64 * 3)(), C.c_double(0.0)
         L.coral_bam_decode_stats(dh, st, C.byref(secs))
-        gst, gsecs = (C.c_int64 * 4)(), (C.c_double * 2)()
+        gst, gsecs = (C.c_int64 * 4)(), (C.c_double * 6)()
         L.coral_bamgpu_stats(h, gst, gsecs)
         LAST_DECODE.clear()
         LAST_DECODE.update(seconds=float(gsecs[0]), compressed_bytes=int(st[0]), uncompressed_bytes=int(st[1]), blocks=int(st[2]),
                            threads=int(n_threads), where="gpu", batches=int(gst[0]), rewalked_segments=int(gst[1]),
-                           nonacgt_records_fetched=int(gst[2]), batch_bytes=int(gst[3]), host_seconds=float(gsecs[1]),
+                           nonacgt_records_fetched=int(gst[2]), batch_bytes=int(gst[3]), host_seconds=float(gsecs[1]), read_seconds=float(gsecs[2]),
+                           setup_seconds=float(gsecs[3]), waited_for_file_seconds=float(gsecs[4]), waited_for_gpu_seconds=float(gsecs[5]),
                            workspace_bytes=int(ws_bytes.value))
         rec = _records_from_handle(L, dh, cigar, total)
         del ws

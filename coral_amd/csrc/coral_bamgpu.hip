@@ -38,6 +38,9 @@ namespace {
 #define CARRY_CAP (64ll << 20)           // room in front of a batch for the head of a straddling record
 #define COMP_SLACK 4096                  // readable bytes behind the compressed batch (the input window reads ahead)
 #define OVERHANG_BLOCKS 1024             // blocks behind a byte range its last record may straddle into (as coral_bam.cpp)
+#define N_STAGE 4                        // pinned staging buffers of the feeder (file -> pinned -> device, round robin)
+#define STAGE_BYTES (32ull << 20)
+#define FIRST_BATCH (64ull << 20)        // inflated bytes of the first batch; the following ones double up to the cap
 
 struct BlockDesc {
     uint32_t src_off;     // first DEFLATE byte, relative to the compressed batch
@@ -49,47 +52,58 @@ struct BlockDesc {
 // ---------------------------------------------------------------------------------------------
 // K_inflate
 // ---------------------------------------------------------------------------------------------
-#define RING_BYTES 1024                  // recent output per wave, in LDS: LZ77 matches read it instead of global memory
+#ifndef RING_LOG
+#define RING_LOG 12
+#endif
+#define RING_BYTES (1 << RING_LOG)       // recent output per wave, in LDS: LZ77 matches read it instead of global memory
 #define RING_MASK (RING_BYTES - 1)
 
+// Backend of coral_inflate::Inflater for one wave (the symbol loop is Inflater::codes_vector).
 // Output positions are counted in "aligned coordinates" A = (out & 255) + o, so that A = 0 is a 256-byte line of global memory:
-// ring index = A & RING_MASK, global address = gbase + A.  Literals are parked in a register (v_writelane into lane A & 63) and
-// written to the ring 64 at a time; matches copy ring -> ring (global -> ring when the source has left the ring); completed
-// 256-byte lines go to global memory as one dword store per lane.  Input: two registers of 64 dwords each, used alternately
-// (the bit buffer is refilled with v_readlane, never from memory).
-struct DevWave {
-    static constexpr bool paired_literals = true;       // coral_inflate_core.h: Inflater::codes_paired is the symbol loop
+// ring index = A & RING_MASK, global address = gbase + A.  Every byte goes to the ring first (a literal: one ds_write_b8 of all
+// lanes to the same address; a match: ring -> ring, or global -> ring when the source has left the ring); each time the
+// position crosses a 256-byte line, the completed lines go to global memory as one dword store per lane.
+// Input: two registers of 64 dwords each, used alternately (the bit buffer is refilled with v_readlane, never from memory).
+// ABLATE (timing experiments of tools/bench_inflate.py only; 0 in the product): 1 = no stores to global memory, 2 = matches whose
+// source left the ring read the ring anyway, 4 = no match copy, 8 = no literal write.
+template <int ABLATE>
+struct DevWaveT {
+    static constexpr bool vector_loop = true;
     int lane;
+    float lane_half;            // lane + 0.5
     const char *in_base;        // dword-aligned start of the stream's input window (global memory)
-    long long stream_off;       // first byte of the DEFLATE stream, relative to in_base (0..3)
-    long long stream_len;
-    long long base_dw;          // dword index (from in_base) the Inflater's `dwords` counts from
-    long long win;              // dword index of lane 0 of r0
-    long long last_dw;          // dword index of the stream's last byte
+    int stream_off;             // first byte of the DEFLATE stream, relative to in_base (0..3)
+    int stream_len;
+    int base_dw;                // dword index (from in_base) the Inflater's `dwords` counts from
+    int win;                    // dword index of lane 0 of r0
+    int last_dw;                // dword index of the stream's last byte
+    int pulled, pull_limit;     // dwords handed out; more than the limit = the stream is corrupt
     uint32_t r0, r1;            // lane i: dwords win + i and win + 64 + i of the input
     int idx;                    // next dword of the 128 (0..63: r0, 64..127: r1)
-    long long pulled;           // dwords handed out in total
     uint8_t *gbase;             // out - (out & 255)
     uint8_t *ring;              // LDS, RING_BYTES
-    int cap;                    // output bytes of the block
-    int a0;                     // out & 255
-    int abase, slot;            // next output byte = abase + slot (aligned coordinates; abase a multiple of 64, slot 0..63)
-    int pfrom, gdone;           // first parked literal, first byte not yet in global memory
-    uint32_t pend;
-    bool over;                  // more output than the block may have (the excess is dropped)
+    int a0, aend;               // aligned coordinates of the block's first byte and of the byte behind its last
+    int a;                      // next output byte
+    int gdone;                  // first byte not yet in global memory
+    int attend;                 // the symbol loop calls attention() once `a` has reached this: a 256-byte line is complete (or,
+                                // set to a - 1 by the rare paths, `over` was raised)
+    uint32_t badv;              // (vector) a distance reached in front of the output
+    bool over;                  // more output than the block may have, or more input than the stream holds: stop
 
     __device__ __forceinline__ uint32_t uni(uint32_t x) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
-    // keeps the table-index arithmetic of the symbol loop on the vector pipe (the scalar pipe is the busy one)
-    __device__ __forceinline__ uint32_t vec(uint32_t x) const {
+    __device__ __forceinline__ uint32_t vec(uint32_t x) const {      // keeps what is computed from x on the vector pipe
         asm("" : "+v"(x));
         return x;
     }
+    __device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t off, uint32_t width) const { return __builtin_amdgcn_ubfe(x, off, width); }
+    __device__ __forceinline__ bool bad() const { return uni(badv) != 0u; }
+    __device__ __forceinline__ bool needs_attention() const { return a >= attend; }
     // Input window loads never start behind the stream's last dword: a corrupt stream that keeps asking for input re-reads the
-    // end (and is reported by input_exhausted) instead of walking out of the compressed buffer (which is readable COMP_SLACK
-    // bytes beyond its last stream, more than one 256-byte window).
-    __device__ __forceinline__ uint32_t input_load(long long dw) const {
-        const long long d = dw < last_dw ? dw : last_dw;
-        return *reinterpret_cast<const uint32_t *>(in_base + d * 4 + lane * 4);
+    // end (and is stopped by the pull limit) instead of walking out of the compressed buffer (readable COMP_SLACK bytes beyond
+    // its last stream, more than one 256-byte window).
+    __device__ __forceinline__ uint32_t input_load(int dw) const {
+        const int d = dw < last_dw ? dw : last_dw;
+        return *reinterpret_cast<const uint32_t *>(in_base + (uint32_t)(d * 4 + lane * 4));
     }
     __device__ __forceinline__ void load_window() {
         r0 = input_load(win);
@@ -98,7 +112,10 @@ struct DevWave {
     }
     __device__ __forceinline__ uint32_t next_dword() {
         uint32_t v;
-        ++pulled;
+        if (++pulled > pull_limit) {
+            over = true;
+            attend = a - 1;
+        }
         if (idx < WAVE) {
             v = (uint32_t)__builtin_amdgcn_readlane((int)r0, idx);
             if (++idx == WAVE) r0 = input_load(win + 2 * WAVE);     // r0 is used up: refill it for the turn after r1's
@@ -112,121 +129,108 @@ struct DevWave {
         }
         return v;
     }
-    __device__ __forceinline__ bool input_exhausted() const { return pulled * 4 > stream_len + 16; }
-    __device__ __forceinline__ int pos() const { return abase + slot; }
-    __device__ __forceinline__ void set_pos(int a) {
-        abase = a & ~63;
-        slot = a & 63;
-    }
-    // parked literals -> ring
-    __device__ __forceinline__ void flush() {
-        const int a = pos();
-        if (pfrom < a) {
-            const int p = (pfrom & ~63) + lane;                        // the parked bytes lie inside one 64-byte window
-            if (p >= pfrom && p < a) ring[p & RING_MASK] = (uint8_t)pend;
-            pfrom = a;
-        }
-    }
-    // completed 256-byte lines ring -> global memory (the block's first line may start inside a line: byte stores there)
-    __device__ __forceinline__ void drain() {
-        const int a = pos();
-        if (a - gdone < 256) return;
-        if (gdone & 255) {
-            const int upto = (gdone | 255) + 1;
-#pragma nounroll
-            for (int p = gdone + lane; p < upto; p += WAVE) gbase[p] = ring[p & RING_MASK];
-            gdone = upto;
-        }
-#pragma nounroll
-        while (a - gdone >= 256) {
-            const int p = gdone + 4 * lane;
-            *reinterpret_cast<uint32_t *>(gbase + p) = *reinterpret_cast<const uint32_t *>(ring + (p & RING_MASK));
-            gdone += 256;
-        }
-    }
-    __device__ __forceinline__ void clamp() {                         // never hand more than `cap` bytes to flush / drain
-        if (pos() - a0 > cap) {
-            over = true;
-            set_pos(a0 + cap);
-            if (pfrom > a0 + cap) pfrom = a0 + cap;
-        }
-    }
-    __device__ __forceinline__ void finish() {                        // everything left goes out byte by byte
-        clamp();
-        flush();
-        const int a = pos();
-#pragma nounroll
-        for (int p = gdone + lane; p < a; p += WAVE) gbase[p] = ring[p & RING_MASK];
-        gdone = a;
-    }
-    __device__ __forceinline__ void window_full() {                   // slot == 64
-        abase += 64;
-        slot = 0;
-        clamp();
-        flush();
+    __device__ __forceinline__ bool input_exhausted() const { return pulled > pull_limit; }
+    __device__ __forceinline__ uint8_t *ring_at(uint32_t av) const { return ring + (av & RING_MASK); }
+    // completed 256-byte lines ring -> global memory (the block's first line may start inside a line: byte stores there);
+    // never beyond the block's last byte
+    // Called by the symbol loop once per round when a >= attend; false = stop decoding.
+    __device__ __forceinline__ bool attention() {
         drain();
+        return !over;
     }
-    // `b`: the byte, as a per-lane or a uniform value (the hot loop passes the table entry's byte straight from the vector
-    // register it was loaded into: extract, compare, select — three vector instructions and no scalar one)
-    __device__ __forceinline__ void put_literal(uint32_t b) {
-        pend = lane == slot ? b : pend;
-        if (++slot == 64) window_full();
+    __device__ __forceinline__ void drain() {
+        if (a > aend) over = true;
+        const int upto = (a < aend ? a : aend) & ~255;
+        int g = gdone;
+        if ((g & 255) && g < upto) {
+            const int head = (g | 255) + 1;
+_Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
+            for (int p = g + lane; p < head; p += WAVE) gbase[p] = *ring_at((uint32_t)p);
+            g = head;
+        }
+_Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
+        for (; g < upto; g += 256) {
+            const int p = g + 4 * lane;
+            if (!(ABLATE & 1)) *reinterpret_cast<uint32_t *>(gbase + p) = *reinterpret_cast<const uint32_t *>(ring_at((uint32_t)p));
+        }
+        gdone = (int)uni((uint32_t)g);
+        attend = over ? a - 1 : (gdone | 255) + 1;
     }
-    __device__ __forceinline__ bool copy_match(int len, int dist) {
-        const int a = pos();
-        if (dist > a - a0) return false;
-        flush();
-        if (dist <= RING_BYTES - 64) {
-            if (dist >= WAVE || dist >= len) {
-                // chunks of 64 bytes in order: a chunk's sources were written by earlier chunks at the latest (LDS is in order)
-#pragma nounroll
-                for (int k = lane; k < len; k += WAVE) ring[(a + k) & RING_MASK] = ring[(a + k - dist) & RING_MASK];
-            } else {                                             // a pattern of period `dist` < 64: byte k = pattern[k mod dist]
-                const uint32_t m = ((1u << 20) + (uint32_t)dist - 1u) / (uint32_t)dist;      // exact for k < 258 (error < 258 / 2^20 < 1 / dist)
-#pragma nounroll
-                for (int k = lane; k < len; k += WAVE) {
-                    const uint32_t q = ((uint32_t)k * m) >> 20;
-                    ring[(a + k) & RING_MASK] = ring[(a - dist + k - (int)(q * (uint32_t)dist)) & RING_MASK];
-                }
+    __device__ __forceinline__ void finish() {                        // what is left goes out byte by byte
+        drain();
+        const int end = a < aend ? a : aend;
+_Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
+        for (int p = gdone + lane; p < end; p += WAVE) gbase[p] = *ring_at((uint32_t)p);
+        gdone = end;
+    }
+    __device__ __forceinline__ void lit(uint32_t bytev) {
+        if (!(ABLATE & 8)) *ring_at(vec((uint32_t)a)) = (uint8_t)bytev;
+        ++a;
+    }
+    __device__ __forceinline__ void put_literal(uint32_t b) { lit(b); }
+    // lenv, distv: the same value in every lane (vector registers)
+    __device__ __forceinline__ void match(uint32_t lenv, uint32_t distv) {
+        const uint32_t av = vec((uint32_t)a);
+        const uint32_t room = vec((uint32_t)(aend - a));              // (a <= aend + 255; as unsigned a huge room then, `over` is raised by drain)
+        const uint32_t far_back = distv > av - (uint32_t)a0 ? 1u : 0u;    // reaches in front of the block's output: corrupt
+        badv |= far_back;
+        lenv = far_back ? 0u : (lenv < room ? lenv : room);
+        const int len = (int)uni(lenv);
+        const uint32_t dist = uni(distv);
+        if (ABLATE & 4) {
+            a += len;
+            return;
+        }
+        if (dist <= RING_BYTES - 64 || (ABLATE & 2)) {
+            // byte k of the match = byte (k mod dist) of the dist bytes in front of it (k mod dist = k when dist >= 64 > lane)
+            const float rd = __builtin_amdgcn_rcpf((float)distv);
+            auto copy = [&](uint32_t k, float kh) {
+                const uint32_t q = (uint32_t)(kh * rd);               // floor((k + 0.5) / dist): exact, (k + 0.5) / dist is >= 0.5 / dist off an integer
+                const uint32_t km = distv < 64u ? k - q * distv : k;
+                if (k < lenv) *ring_at(av + k) = *ring_at(av - distv + km);
+            };
+            copy((uint32_t)lane, lane_half);
+            if (len > WAVE) {                                         // chunks in order: LDS operations of a wave execute in order
+_Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
+                for (int k = lane + WAVE; k < len; k += WAVE) copy((uint32_t)k, (float)k + 0.5f);
             }
         } else {
-            // the source left the ring: it is in global memory (drained up to a - 255 at least; a - dist + len lies below that)
-            const uint8_t *src = gbase + (a - dist);
-#pragma nounroll
-            for (int k = lane; k < len; k += WAVE) ring[(a + k) & RING_MASK] = src[k];
+            // the source left the ring: it is in global memory (drained up to the last line boundary; a - dist + len lies below it)
+            const uint8_t *src = gbase + (a - (int)dist);
+_Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
+            for (int k = lane; k < len; k += WAVE) *ring_at(av + (uint32_t)k) = src[k];
         }
-        set_pos(a + len);
-        pfrom = a + len;
-        drain();
+        a += len;
+    }
+    __device__ __forceinline__ bool copy_match(int len, int dist) {   // (the plain loop's interface; unused on the device)
+        match((uint32_t)len, (uint32_t)dist);
         return true;
     }
-    __device__ __forceinline__ bool copy_stored(long long dwords, uint32_t n) {
-        const long long from = 4 * (base_dw + dwords) - stream_off;       // relative to the stream
-        if (from < 0 || from + (long long)n > stream_len) return false;
-        flush();
+    __device__ __forceinline__ bool copy_stored(int dwords, uint32_t n) {
+        const int from = 4 * (base_dw + dwords) - stream_off;          // relative to the stream
+        if (from < 0 || from + (int)n > stream_len) return false;
         const uint8_t *src = reinterpret_cast<const uint8_t *>(in_base) + stream_off + from;
-#pragma nounroll
+_Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
         for (uint32_t done = 0; done < n;) {                      // through the ring, 256 bytes at a time (it is drained in step)
             const uint32_t step = n - done < 256u ? n - done : 256u;
-            const int a = pos();
-#pragma nounroll
-            for (uint32_t k = (uint32_t)lane; k < step; k += WAVE) ring[(a + (int)k) & RING_MASK] = src[done + k];
-            set_pos(a + (int)step);
-            pfrom = a + (int)step;
+_Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
+            for (uint32_t k = (uint32_t)lane; k < step; k += WAVE) *ring_at((uint32_t)a + k) = src[done + k];
+            a += (int)step;
             drain();
             done += step;
         }
         return true;
     }
-    __device__ __forceinline__ uint32_t reset_input_after_stored(long long dwords, uint32_t n) {
-        const long long byte = 4 * (base_dw + dwords) + (long long)n;
+    __device__ __forceinline__ uint32_t reset_input_after_stored(int dwords, uint32_t n) {
+        const int byte = 4 * (base_dw + dwords) + (int)n;
         base_dw = byte >> 2;
         win = base_dw;
+        pulled = base_dw;
         load_window();
         return (uint32_t)(byte & 3) * 8u;
     }
-    __device__ __forceinline__ int produced() const { return pos() - a0; }
-    __device__ __forceinline__ int capacity() const { return cap; }
+    __device__ __forceinline__ int produced() const { return a - a0; }
+    __device__ __forceinline__ int capacity() const { return aend - a0; }
     __device__ __forceinline__ void add_count(uint32_t *c) { atomicAdd(c, 1u); }
     __device__ __forceinline__ void fence() {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -234,7 +238,10 @@ struct DevWave {
     }
 };
 
-#define INFL_WAVES 4
+typedef DevWaveT<0> DevWave;
+
+#define INFL_WAVES 1                     // one wave per workgroup: LDS (tables + ring, 7.7 KiB) is allocated per wave
+template <int ABLATE>
 __global__ __launch_bounds__(INFL_WAVES *WAVE) void k_bgzf_inflate(const uint8_t *__restrict__ comp, const BlockDesc *__restrict__ desc,
                                                                      int n_blocks, uint8_t *out, int32_t *__restrict__ status) {
     __shared__ coral_inflate::Tables tables[INFL_WAVES];
@@ -248,31 +255,33 @@ __global__ __launch_bounds__(INFL_WAVES *WAVE) void k_bgzf_inflate(const uint8_t
         if (lane == 0) status[b] = 0;
         return;
     }
-    // (comp and out are 4- resp. 1-byte aligned allocations of the caller; pointers keep their kernel-argument provenance so
-    // that the loads and stores are global_*, not flat_*)
+    // (comp is a 4-byte aligned allocation of the caller; pointers keep their kernel-argument provenance so that the loads and
+    // stores are global_*, not flat_*)
     const uint32_t mis = (uint32_t)(((uintptr_t)comp + d.src_off) & 3u);
-    DevWave w;
+    DevWaveT<ABLATE> w;
     w.lane = lane;
+    w.lane_half = (float)lane + 0.5f;
     w.in_base = reinterpret_cast<const char *>(comp) + (d.src_off - mis);
-    w.stream_off = mis;
-    w.stream_len = d.src_len;
+    w.stream_off = (int)mis;
+    w.stream_len = (int)d.src_len;
     w.base_dw = 0;
     w.win = 0;
-    w.last_dw = ((long long)mis + d.src_len) >> 2;
+    w.last_dw = (int)((mis + d.src_len) >> 2);
     w.pulled = 0;
+    w.pull_limit = w.last_dw + 5;
     w.a0 = (int)(((uintptr_t)out + d.dst_off) & 255u);
+    w.aend = w.a0 + (int)d.isize;
     w.gbase = out + ((long long)d.dst_off - w.a0);
     w.ring = rings[wib];
-    w.cap = (int)d.isize;
-    w.set_pos(w.a0);
-    w.pfrom = w.gdone = w.a0;
-    w.pend = 0;
-    w.r0 = w.r1 = 0;
+    w.a = w.gdone = w.a0;
+    w.attend = (w.a0 | 255) + 1;
+    w.badv = 0;
     w.over = false;
     w.load_window();
-    coral_inflate::Inflater<DevWave> inf(w, &tables[wib]);
-    const int rc = inf.run((int)mis * 8);
+    coral_inflate::Inflater<DevWaveT<ABLATE>> inf(w, &tables[wib]);
+    int rc = inf.run((int)mis * 8);
     w.finish();
+    if (rc == coral_inflate::OK && (w.over || w.bad())) rc = coral_inflate::ERR_OVERFLOW;
     if (lane == 0) status[b] = rc;
 }
 
@@ -605,6 +614,18 @@ __global__ __launch_bounds__(256) void k_bam_emit(const uint8_t *__restrict__ bu
     }
 }
 
+// whole records (the rare ones with non-ACGT bases) -> one contiguous buffer for the host: one wave per record
+__global__ __launch_bounds__(256) void k_bam_gather(const uint8_t *__restrict__ buf, const long long *__restrict__ src, const long long *__restrict__ dst,
+                                                     const long long *__restrict__ len, int n, uint8_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int j = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (j >= n) return;
+    const uint8_t *s = buf + src[j];
+    uint8_t *d = out + dst[j];
+    const long long m = len[j];
+    for (long long k = lane; k < m; k += WAVE) d[k] = s[k];
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -617,6 +638,17 @@ struct BatchInfo {
     bool has_limit = false;          // the next byte range begins at or in front of this batch's end:
     long long limit_rel = 0;         //   at this offset from the batch's first inflated byte (negative: in an earlier batch)
     bool last = false;               // nothing follows
+};
+
+// what a batch leaves for the host-side worker: read names -> ids, SA text -> rows, non-ACGT records -> positions
+struct HostJob {
+    size_t base = 0;                 // ordinal of the batch's first record in the decoded range
+    long long n = 0;
+    std::vector<long long> pad, name_off, sa_off;
+    std::vector<uint8_t> names, sa_text;
+    std::vector<int32_t> na_list;    // (sorted) batch-local ordinals of the records with a non-ACGT code
+    std::vector<long long> na_off;   // their bytes in na_raw (n + 1 offsets); a record = its bytes behind block_size
+    std::vector<uint8_t> na_raw;
 };
 
 struct GpuDecoder {
@@ -644,9 +676,12 @@ struct GpuDecoder {
     void *d_scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0, names_cap = 0, sa_cap = 0;
     // pinned staging + streams
-    uint8_t *h_stage[2] = {nullptr, nullptr};
+    uint8_t *h_stage[N_STAGE] = {};
+    BlockDesc *h_desc[2] = {nullptr, nullptr};
     hipStream_t s_copy = nullptr, s_infl = nullptr;
+    hipEvent_t ev_stage[N_STAGE] = {};
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_infl[2] = {nullptr, nullptr}, ev_parsed[2] = {nullptr, nullptr};
+    double t_read = 0, t_alloc = 0, t_wait_staged = 0, t_wait_gpu = 0;
     // feeder
     std::thread feeder;
     std::mutex m;
@@ -665,6 +700,14 @@ struct GpuDecoder {
     long long cur_n_rec = 0, cur_ops = 0, cur_name_bytes = 0, cur_sa_bytes = 0;
     bool have_cur = false;
     std::unordered_map<std::string, int32_t> name_id;
+    // host-side worker
+    std::thread worker;
+    std::mutex wm;
+    std::condition_variable wcv;
+    std::deque<std::unique_ptr<HostJob>> jobs;
+    bool worker_stop = false, worker_busy = false;
+    std::string worker_error;
+    long long cur_carry_pos = 0;
     // statistics
     double t_open = 0, seconds = 0, host_seconds = 0;
     int64_t fixups = 0, n_batches = 0, na_records = 0;
@@ -677,8 +720,18 @@ struct GpuDecoder {
         }
         cv.notify_all();
         if (feeder.joinable()) feeder.join();
-        for (int i = 0; i < 2; ++i) {
+        {
+            std::lock_guard<std::mutex> lk(wm);
+            worker_stop = true;
+        }
+        wcv.notify_all();
+        if (worker.joinable()) worker.join();
+        for (int i = 0; i < N_STAGE; ++i) {
             if (h_stage[i]) (void)hipHostFree(h_stage[i]);
+            if (ev_stage[i]) (void)hipEventDestroy(ev_stage[i]);
+        }
+        for (int i = 0; i < 2; ++i) {
+            if (h_desc[i]) (void)hipHostFree(h_desc[i]);
             if (ev_h2d[i]) (void)hipEventDestroy(ev_h2d[i]);
             if (ev_infl[i]) (void)hipEventDestroy(ev_infl[i]);
             if (ev_parsed[i]) (void)hipEventDestroy(ev_parsed[i]);
@@ -724,13 +777,14 @@ void feeder_main(GpuDecoder *G) {
     uint64_t ubase = 0;
     long long own_bytes = -1;                 // known once the first block of the next range has been seen
     size_t overhang_left = OVERHANG_BLOCKS;
-    int kb = 0;
+    int kb = 0, chunk_no = 0;
     auto fail = [&](const std::string &msg) {
         std::lock_guard<std::mutex> lk(G->m);
         G->feeder_error = msg;
         G->feeder_done = true;
         G->cv.notify_all();
     };
+    std::vector<BlockDesc> desc;
     for (;;) {
         const int slot = kb & 1;
         if (at >= G->f.size || (own_bytes >= 0 && overhang_left == 0)) break;
@@ -740,56 +794,78 @@ void feeder_main(GpuDecoder *G) {
             if (G->stop) return;
         }
         if (kb >= 2 && hipEventSynchronize(G->ev_infl[slot]) != hipSuccess) return fail("hipEventSynchronize failed in the feeder");
-        const size_t want = (size_t)std::min<uint64_t>(G->comp_cap, G->f.size - at);
-        uint8_t *stage = G->h_stage[slot];
-        const size_t desc_bytes = up256(G->max_blocks * sizeof(BlockDesc));
-        uint8_t *data = stage + desc_bytes;
-        if (!read_range(G->f.fd, at, want, data, G->n_threads)) return fail("reading the BAM file failed");
-        BlockDesc *desc = (BlockDesc *)stage;
+        // the first batches are small so that the GPU has something to inflate almost at once; then they double up to the cap
+        const uint64_t infl_cap = std::min<uint64_t>(G->infl_cap, (uint64_t)FIRST_BATCH << std::min(kb, 20));
+        const uint64_t comp_cap = std::min<uint64_t>(G->comp_cap, std::max<uint64_t>(infl_cap / 2, 1u << 20));
         BatchInfo bi;
         bi.file_off = at;
         bi.ubase = ubase;
-        size_t p = 0;
-        uint64_t infl = 0;
-        while (p < want && (size_t)bi.n_blocks < G->max_blocks) {
-            Block b;
-            if (!bgzf_header(data + p, want - p, b)) {
-                if (want - p >= 65536 + 26 || at + want >= G->f.size) return fail("not a BGZF block");
-                break;                                             // the block continues behind what was read
-            }
-            if (infl + b.isize > G->infl_cap) break;
-            const bool owned = at + p < G->byte_hi;
-            if (!owned) {
-                if (own_bytes < 0) {
-                    own_bytes = (long long)(ubase + infl);
+        desc.clear();
+        uint64_t comp = 0, infl = 0;          // bytes of the batch so far
+        bool full = false;
+        while (!full && at < G->f.size) {
+            // one chunk: read -> walk its whole BGZF blocks -> send them behind what the batch already has
+            const int cs = chunk_no % N_STAGE;
+            if (chunk_no >= N_STAGE && hipEventSynchronize(G->ev_stage[cs]) != hipSuccess) return fail("hipEventSynchronize failed in the feeder");
+            const size_t want = (size_t)std::min<uint64_t>(std::min<uint64_t>(STAGE_BYTES, comp_cap - comp), G->f.size - at);
+            if (want < 28) break;
+            uint8_t *data = G->h_stage[cs];
+            const auto t0 = std::chrono::steady_clock::now();
+            if (!read_range(G->f.fd, at, want, data, G->n_threads)) return fail("reading the BAM file failed");
+            G->t_read += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            size_t p = 0;
+            while (p < want) {
+                if (desc.size() >= G->max_blocks) { full = true; break; }
+                Block b;
+                if (!bgzf_header(data + p, want - p, b)) {
+                    if (want - p >= 65536 + 26 || at + want >= G->f.size) return fail("not a BGZF block");
+                    if (want < STAGE_BYTES) full = true;           // the block does not fit what is left of the batch
+                    break;                                         // the block continues behind what was read
                 }
-                if (overhang_left == 0) break;
-                --overhang_left;
+                if (infl + b.isize > infl_cap) { full = true; break; }
+                const bool owned = at + p < G->byte_hi;
+                if (!owned) {
+                    if (own_bytes < 0) own_bytes = (long long)(ubase + infl);
+                    if (overhang_left == 0) { full = true; break; }
+                    --overhang_left;
+                }
+                BlockDesc d;
+                d.src_off = (uint32_t)(comp + p + b.hdr);
+                d.src_len = b.csize - b.hdr - 8;
+                d.dst_off = (uint32_t)infl;
+                d.isize = b.isize;
+                desc.push_back(d);
+                infl += b.isize;
+                p += b.csize;
+                if (owned) { G->D.compressed_bytes += b.csize; G->D.uncompressed_bytes += b.isize; ++G->D.n_blocks; }
             }
-            BlockDesc &d = desc[bi.n_blocks++];
-            d.src_off = (uint32_t)(p + b.hdr);
-            d.src_len = b.csize - b.hdr - 8;
-            d.dst_off = (uint32_t)infl;
-            d.isize = b.isize;
-            infl += b.isize;
-            p += b.csize;
-            if (owned) { G->D.compressed_bytes += b.csize; G->D.uncompressed_bytes += b.isize; ++G->D.n_blocks; }
+            if (p == 0) {
+                if (desc.empty()) return fail("a BGZF block does not fit the batch buffers");
+                break;
+            }
+            if (hipMemcpyAsync(G->d_comp[slot] + comp, data, p, hipMemcpyHostToDevice, G->s_copy) != hipSuccess ||
+                hipEventRecord(G->ev_stage[cs], G->s_copy) != hipSuccess)
+                return fail("host-to-device copy of compressed bytes failed");
+            ++chunk_no;
+            comp += p;
+            at += p;
+            if (comp + 65536 + 26 > comp_cap) full = true;
         }
-        if (bi.n_blocks == 0) return fail("a BGZF block does not fit the batch buffers");
-        bi.comp_bytes = p;
+        if (desc.empty()) break;
+        bi.n_blocks = (int)desc.size();
+        bi.comp_bytes = comp;
         bi.infl_bytes = infl;
         if (own_bytes >= 0) {
             bi.has_limit = true;
             bi.limit_rel = own_bytes - (long long)ubase;
         }
-        at += p;
         ubase += infl;
         bi.last = at >= G->f.size || (own_bytes >= 0 && overhang_left == 0);
-        if (hipMemcpyAsync(G->d_desc[slot], desc, (size_t)bi.n_blocks * sizeof(BlockDesc), hipMemcpyHostToDevice, G->s_copy) != hipSuccess ||
-            hipMemcpyAsync(G->d_comp[slot], data, p, hipMemcpyHostToDevice, G->s_copy) != hipSuccess ||
+        // the block table goes through its own pinned buffer (one per batch slot; reused after the slot's inflate, see above)
+        memcpy(G->h_desc[slot], desc.data(), desc.size() * sizeof(BlockDesc));
+        if (hipMemcpyAsync(G->d_desc[slot], G->h_desc[slot], desc.size() * sizeof(BlockDesc), hipMemcpyHostToDevice, G->s_copy) != hipSuccess ||
             hipEventRecord(G->ev_h2d[slot], G->s_copy) != hipSuccess)
-            return fail("host-to-device copy of a compressed batch failed");
-        // (the staging slot is reused two batches later, after the inflate of this batch — hence after this copy — has run)
+            return fail("host-to-device copy of a block table failed");
         {
             std::lock_guard<std::mutex> lk(G->m);
             G->staged.push_back(bi);
@@ -803,6 +879,72 @@ void feeder_main(GpuDecoder *G) {
         G->feeder_done = true;
     }
     G->cv.notify_all();
+}
+
+// The host-side worker: batches in file order.  Touches only D.cigar_off, D.name_id, D.names, D.sa, D.sa_nm, D.sa_off, D.na_rec,
+// D.na_pos (the caller's thread fills the per-record integer columns).
+void worker_main(GpuDecoder *G) {
+    Decoded &D = G->D;
+    for (;;) {
+        std::unique_ptr<HostJob> job;
+        {
+            std::unique_lock<std::mutex> lk(G->wm);
+            G->wcv.wait(lk, [&] { return G->worker_stop || !G->jobs.empty(); });
+            if (G->jobs.empty()) return;
+            job = std::move(G->jobs.front());
+            G->jobs.pop_front();
+            G->worker_busy = true;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        std::string err;
+        HostJob &J = *job;
+        for (long long i = 0; i < J.n && err.empty(); ++i) {
+            D.cigar_off.push_back(D.cigar_off.back() + J.pad[(size_t)i]);
+            const char *s = (const char *)J.names.data() + J.name_off[(size_t)i];
+            const size_t len = (size_t)(J.name_off[(size_t)i + 1] - J.name_off[(size_t)i]);
+            std::string nmstr(s, len ? strnlen(s, len - 1) : 0);          // as the CPU pipeline: the bytes in front of the last one, cut at a NUL
+            auto it = G->name_id.find(nmstr);
+            if (it == G->name_id.end()) {
+                it = G->name_id.emplace(nmstr, (int32_t)D.names.size()).first;
+                D.names.push_back(nmstr);
+            }
+            D.name_id.push_back(it->second);
+            int32_t cnt = 0;
+            if (J.sa_off[(size_t)i + 1] > J.sa_off[(size_t)i]) {
+                const char *q = (const char *)J.sa_text.data() + J.sa_off[(size_t)i];
+                const char *qe = q + (J.sa_off[(size_t)i + 1] - J.sa_off[(size_t)i]);
+                while (q < qe && *q) {
+                    const char *e = q;
+                    while (e < qe && *e && *e != ';') ++e;
+                    if (e > q) {
+                        int32_t row[8], snm = 0;
+                        if (!parse_sa_entry(q, e, G->ref_id, row, &snm)) { err = "malformed SA entry"; break; }
+                        D.sa.insert(D.sa.end(), row, row + 8);
+                        D.sa_nm.push_back(snm);
+                        ++cnt;
+                    }
+                    q = (e < qe && *e == ';') ? e + 1 : e;
+                }
+            }
+            D.sa_off.push_back(D.sa_off.back() + cnt);
+        }
+        // records with a non-ACGT code: their aligned non-ACGT positions come from the CPU pipeline's own routine
+        for (size_t j = 0; j < J.na_list.size() && err.empty(); ++j) {
+            Partial pt;
+            if (!decode_record(J.na_raw.data() + J.na_off[j], (uint32_t)(J.na_off[j + 1] - J.na_off[j]), G->ref_id, pt, err)) break;
+            for (size_t q = 0; q < pt.na_pos.size(); ++q) {
+                D.na_rec.push_back((int64_t)J.base + J.na_list[j]);
+                D.na_pos.push_back(pt.na_pos[q]);
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(G->wm);
+            G->host_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (!err.empty() && G->worker_error.empty()) G->worker_error = err;
+            G->worker_busy = false;
+        }
+        G->wcv.notify_all();
+    }
 }
 
 bool carve(GpuDecoder *G, void *ws, size_t bytes) {
@@ -852,7 +994,7 @@ bool launch_inflate(GpuDecoder *G, int kb, const BatchInfo &bi) {
     HIP_OK(hipStreamWaitEvent(G->s_infl, G->ev_h2d[slot], 0), "hipStreamWaitEvent");
     if (kb >= 2) HIP_OK(hipStreamWaitEvent(G->s_infl, G->ev_parsed[slot], 0), "hipStreamWaitEvent");     // the buffer's previous batch has been parsed
     const int grid = (bi.n_blocks + INFL_WAVES - 1) / INFL_WAVES;
-    hipLaunchKernelGGL(k_bgzf_inflate, dim3(grid), dim3(INFL_WAVES * WAVE), 0, G->s_infl, G->d_comp[slot], G->d_desc[slot], bi.n_blocks,
+    hipLaunchKernelGGL(k_bgzf_inflate<0>, dim3(grid), dim3(INFL_WAVES * WAVE), 0, G->s_infl, G->d_comp[slot], G->d_desc[slot], bi.n_blocks,
                        G->d_infl[slot] + CARRY_CAP, G->d_status[slot]);
     HIP_OK(hipGetLastError(), "k_bgzf_inflate");
     HIP_OK(hipEventRecord(G->ev_infl[slot], G->s_infl), "hipEventRecord");
@@ -866,8 +1008,10 @@ bool launch_inflate(GpuDecoder *G, int kb, const BatchInfo &bi) {
 
 // wait until batch kb has been staged; false = there is no such batch (or the feeder failed: G->error set)
 bool wait_staged(GpuDecoder *G, int kb, BatchInfo *bi) {
+    const auto t0 = std::chrono::steady_clock::now();
     std::unique_lock<std::mutex> lk(G->m);
     G->cv.wait(lk, [&] { return (int)G->staged.size() > kb || G->feeder_done; });
+    G->t_wait_staged += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (!G->feeder_error.empty()) { G->error = G->feeder_error; return false; }
     if ((int)G->staged.size() <= kb) return false;
     *bi = G->staged[(size_t)kb];
@@ -939,16 +1083,22 @@ extern "C" int coral_bamgpu_start(void *handle, void *workspace, int64_t workspa
     hipError_t e;
     if ((e = hipGetDevice(&G->device)) != hipSuccess) return bad("hipGetDevice", e);
     carve(G, workspace, (size_t)workspace_bytes);
-    const size_t stage_bytes = up256(G->max_blocks * sizeof(BlockDesc)) + G->comp_cap;
+    const auto t_alloc0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < N_STAGE; ++i) {
+        if ((e = hipHostMalloc((void **)&G->h_stage[i], STAGE_BYTES, hipHostMallocDefault)) != hipSuccess) return bad("hipHostMalloc", e);
+        if ((e = hipEventCreateWithFlags(&G->ev_stage[i], hipEventDisableTiming)) != hipSuccess) return bad("hipEventCreate", e);
+    }
     for (int i = 0; i < 2; ++i) {
-        if ((e = hipHostMalloc((void **)&G->h_stage[i], stage_bytes, hipHostMallocDefault)) != hipSuccess) return bad("hipHostMalloc", e);
+        if ((e = hipHostMalloc((void **)&G->h_desc[i], up256(G->max_blocks * sizeof(BlockDesc)), hipHostMallocDefault)) != hipSuccess) return bad("hipHostMalloc", e);
         if ((e = hipEventCreateWithFlags(&G->ev_h2d[i], hipEventDisableTiming)) != hipSuccess) return bad("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&G->ev_infl[i], hipEventDisableTiming)) != hipSuccess) return bad("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&G->ev_parsed[i], hipEventDisableTiming)) != hipSuccess) return bad("hipEventCreate", e);
     }
     if ((e = hipStreamCreateWithFlags(&G->s_copy, hipStreamNonBlocking)) != hipSuccess) return bad("hipStreamCreate", e);
     if ((e = hipStreamCreateWithFlags(&G->s_infl, hipStreamNonBlocking)) != hipSuccess) return bad("hipStreamCreate", e);
+    G->t_alloc = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_alloc0).count();
     G->feeder = std::thread(feeder_main, G);
+    G->worker = std::thread(worker_main, G);
     // inflate of batch 0 starts as soon as it is staged
     BatchInfo b0;
     if (wait_staged(G, 0, &b0)) {
@@ -1009,7 +1159,10 @@ extern "C" int coral_bamgpu_next(void *handle, int64_t out[4], void *stream_) {
     if (have_next && !launch_inflate(G, kb + 1, nb)) return fail(CORAL_ERR_HIP);
     int32_t status_bad = 0;
     if (n_seg > 0) {
-        if (hipMemcpyAsync(res, G->d_result, sizeof(res), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+        const auto t_gpu0 = std::chrono::steady_clock::now();
+        const bool synced = hipMemcpyAsync(res, G->d_result, sizeof(res), hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
+        G->t_wait_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_gpu0).count();
+        if (!synced) {
             G->error = std::string("record walk failed: ") + hipGetErrorString(hipGetLastError());
             return fail(CORAL_ERR_HIP);
         }
@@ -1026,6 +1179,7 @@ extern "C" int coral_bamgpu_next(void *handle, int64_t out[4], void *stream_) {
     if (res[3] == 1) { G->error = "record shorter than its fixed fields"; return fail(CORAL_ERR_FORMAT); }
     if (res[3] == 2) { G->error = "no record start found in the first batch of the byte range"; return fail(CORAL_ERR_FORMAT); }
     const long long n_rec = res[0], carry_pos = res[1];
+    G->cur_carry_pos = carry_pos < data_end ? carry_pos : data_end;
     G->fixups += res[4];
     if (n_rec > (long long)G->rec_cap) { G->error = "more records in a batch than its workspace holds"; return fail(CORAL_ERR_FORMAT); }
     G->searching = false;
@@ -1113,85 +1267,71 @@ extern "C" int coral_bamgpu_emit(void *handle, uint32_t *cigar_dst, int64_t *cig
                            stream) != hipSuccess)
             return fail(CORAL_ERR_HIP, "device copy of the carried bytes failed");
     }
-    const auto t_host0 = std::chrono::steady_clock::now();
     if (n > 0) {
+        std::unique_ptr<HostJob> job(new HostJob());
+        HostJob &J = *job;
         const size_t base = D.tid.size();
+        J.base = base;
+        J.n = n;
         auto grow = [&](std::vector<int32_t> &v) { v.resize(base + (size_t)n); return v.data() + base; };
         int32_t *tid = grow(D.tid), *pos = grow(D.pos), *end = grow(D.end), *flag = grow(D.flag), *mapq = grow(D.mapq), *qlen = grow(D.qlen),
                 *has_seq = grow(D.has_seq), *nm = grow(D.nm), *n_cigar = grow(D.n_cigar);
-        std::vector<long long> pad((size_t)n), name_off((size_t)n + 1), sa_off((size_t)n + 1);
-        std::vector<uint8_t> names((size_t)G->cur_name_bytes), sa_text((size_t)G->cur_sa_bytes);
+        J.pad.resize((size_t)n);
+        J.name_off.resize((size_t)n + 1);
+        J.sa_off.resize((size_t)n + 1);
+        J.names.resize((size_t)G->cur_name_bytes);
+        J.sa_text.resize((size_t)G->cur_sa_bytes);
         int32_t na_count = 0;
         auto get = [&](void *dst, const void *src, size_t bytes) { return bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream) == hipSuccess; };
         const size_t n4 = (size_t)n * 4;
+        const auto t_gpu0 = std::chrono::steady_clock::now();
         bool ok = get(tid, G->M.tid, n4) && get(pos, G->M.pos, n4) && get(end, G->d_end, n4) && get(flag, G->M.flag, n4) && get(mapq, G->M.mapq, n4) &&
                   get(qlen, G->d_qlen, n4) && get(has_seq, G->M.l_seq, n4) && get(nm, G->M.nm, n4) && get(n_cigar, G->M.n_cigar, n4) &&
-                  get(pad.data(), G->M.pad_ops, (size_t)n * 8) && get(name_off.data(), G->d_name_off, (size_t)(n + 1) * 8) &&
-                  get(sa_off.data(), G->d_sa_off, (size_t)(n + 1) * 8) && get(names.data(), G->d_names, names.size()) &&
-                  get(sa_text.data(), G->d_sa_text, sa_text.size()) && get(&na_count, G->d_na_count, 4);
+                  get(J.pad.data(), G->M.pad_ops, (size_t)n * 8) && get(J.name_off.data(), G->d_name_off, (size_t)(n + 1) * 8) &&
+                  get(J.sa_off.data(), G->d_sa_off, (size_t)(n + 1) * 8) && get(J.names.data(), G->d_names, J.names.size()) &&
+                  get(J.sa_text.data(), G->d_sa_text, J.sa_text.size()) && get(&na_count, G->d_na_count, 4);
         if (!ok || hipStreamSynchronize(stream) != hipSuccess) return fail(CORAL_ERR_HIP, std::string("copy of the batch's host fields failed: ") + hipGetErrorString(hipGetLastError()));
-        for (long long i = 0; i < n; ++i) {
-            has_seq[i] = has_seq[i] > 0 ? 1 : 0;                          // (arrived as l_seq)
-            D.cigar_off.push_back(D.cigar_off.back() + pad[(size_t)i]);
-        }
-        // read names -> ids (first appearance order), SA text -> rows
-        for (long long i = 0; i < n; ++i) {
-            const char *s = (const char *)names.data() + name_off[(size_t)i];
-            const size_t len = (size_t)(name_off[(size_t)i + 1] - name_off[(size_t)i]);
-            std::string nmstr(s, len ? strnlen(s, len - 1) : 0);          // as the CPU pipeline: the bytes in front of the last one, cut at a NUL
-            auto it = G->name_id.find(nmstr);
-            if (it == G->name_id.end()) {
-                it = G->name_id.emplace(nmstr, (int32_t)D.names.size()).first;
-                D.names.push_back(nmstr);
-            }
-            D.name_id.push_back(it->second);
-            int32_t cnt = 0;
-            if (sa_off[(size_t)i + 1] > sa_off[(size_t)i]) {
-                const char *q = (const char *)sa_text.data() + sa_off[(size_t)i];
-                const char *qe = q + (sa_off[(size_t)i + 1] - sa_off[(size_t)i]);
-                while (q < qe && *q) {
-                    const char *e = q;
-                    while (e < qe && *e && *e != ';') ++e;
-                    if (e > q) {
-                        int32_t row[8], snm = 0;
-                        if (!parse_sa_entry(q, e, G->ref_id, row, &snm)) return fail(CORAL_ERR_FORMAT, "malformed SA entry");
-                        D.sa.insert(D.sa.end(), row, row + 8);
-                        D.sa_nm.push_back(snm);
-                        ++cnt;
-                    }
-                    q = (e < qe && *e == ';') ? e + 1 : e;
-                }
-            }
-            D.sa_off.push_back(D.sa_off.back() + cnt);
-        }
-        // records with a non-ACGT code: fetched whole, their aligned non-ACGT positions come from the CPU pipeline's routine
+        G->t_wait_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_gpu0).count();
+        for (long long i = 0; i < n; ++i) has_seq[i] = has_seq[i] > 0 ? 1 : 0;       // (arrived as l_seq)
         if (na_count > 0) {
-            std::vector<int32_t> list((size_t)na_count);
+            // the records with a non-ACGT code, whole, in one gather + one copy (the offset arrays of the scans are free by now)
+            J.na_list.resize((size_t)na_count);
             std::vector<long long> starts((size_t)n);
-            if (hipMemcpy(list.data(), G->d_na_list, list.size() * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            if (hipMemcpy(J.na_list.data(), G->d_na_list, (size_t)na_count * 4, hipMemcpyDeviceToHost) != hipSuccess ||
                 hipMemcpy(starts.data(), G->d_rec_start, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess)
                 return fail(CORAL_ERR_HIP, "copy of the non-ACGT list failed");
-            std::sort(list.begin(), list.end());
-            std::vector<uint8_t> raw;
-            for (int32_t li : list) {
-                uint32_t bs = 0;
-                if (hipMemcpy(&bs, buf + starts[(size_t)li], 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(CORAL_ERR_HIP, "copy of a record failed");
-                raw.resize((size_t)bs);
-                if (hipMemcpy(raw.data(), buf + starts[(size_t)li] + 4, bs, hipMemcpyDeviceToHost) != hipSuccess) return fail(CORAL_ERR_HIP, "copy of a record failed");
-                Partial pt;
-                std::string err;
-                if (!decode_record(raw.data(), bs, G->ref_id, pt, err)) return fail(CORAL_ERR_FORMAT, err);
-                for (size_t j = 0; j < pt.na_pos.size(); ++j) {
-                    D.na_rec.push_back((int64_t)base + li);
-                    D.na_pos.push_back(pt.na_pos[j]);
-                }
+            std::sort(J.na_list.begin(), J.na_list.end());
+            std::vector<long long> src((size_t)na_count), dst((size_t)na_count), len((size_t)na_count);
+            J.na_off.assign((size_t)na_count + 1, 0);
+            for (int32_t j = 0; j < na_count; ++j) {
+                const int32_t li = J.na_list[(size_t)j];
+                const long long rec_end = li + 1 < n ? starts[(size_t)li + 1] : G->cur_carry_pos;
+                src[(size_t)j] = starts[(size_t)li] + 4;
+                len[(size_t)j] = rec_end - starts[(size_t)li] - 4;
+                dst[(size_t)j] = J.na_off[(size_t)j];
+                J.na_off[(size_t)j + 1] = J.na_off[(size_t)j] + len[(size_t)j];
             }
+            const long long total = J.na_off[(size_t)na_count];
+            J.na_raw.resize((size_t)total);
+            if ((size_t)total > G->names_cap) return fail(CORAL_ERR_FORMAT, "records with non-ACGT bases exceed the batch workspace");
+            if (hipMemcpy(G->d_cig_off, src.data(), (size_t)na_count * 8, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(G->d_name_off, dst.data(), (size_t)na_count * 8, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(G->d_sa_off, len.data(), (size_t)na_count * 8, hipMemcpyHostToDevice) != hipSuccess)
+                return fail(CORAL_ERR_HIP, "upload of the non-ACGT gather list failed");
+            hipLaunchKernelGGL(k_bam_gather, dim3((unsigned)((na_count + 3) / 4)), dim3(256), 0, stream, buf, G->d_cig_off, G->d_name_off, G->d_sa_off, (int)na_count,
+                               G->d_names);
+            if (hipMemcpyAsync(J.na_raw.data(), G->d_names, (size_t)total, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+                return fail(CORAL_ERR_HIP, "copy of the records with non-ACGT bases failed");
             G->na_records += na_count;
         }
+        {
+            std::lock_guard<std::mutex> lk(G->wm);
+            G->jobs.push_back(std::move(job));
+        }
+        G->wcv.notify_all();
     } else if (hipStreamSynchronize(stream) != hipSuccess) {
         return fail(CORAL_ERR_HIP, "hipStreamSynchronize failed");
     }
-    G->host_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_host0).count();
     // this buffer may be inflated into again (batch k + 2) once everything above has run
     if (hipEventRecord(G->ev_parsed[slot], stream) != hipSuccess) return fail(CORAL_ERR_HIP, "hipEventRecord failed");
     G->have_cur = false;
@@ -1205,17 +1345,28 @@ extern "C" int coral_bamgpu_emit(void *handle, uint32_t *cigar_dst, int64_t *cig
 extern "C" int coral_bamgpu_host(void *handle, void **decoded) {
     GpuDecoder *G = (GpuDecoder *)handle;
     if (!G || !decoded) return CORAL_ERR_ARG;
+    {   // the worker must have taken every batch in
+        std::unique_lock<std::mutex> lk(G->wm);
+        G->wcv.wait(lk, [&] { return G->jobs.empty() && !G->worker_busy; });
+        if (!G->worker_error.empty()) {
+            set_error(G->worker_error);
+            return CORAL_ERR_FORMAT;
+        }
+    }
+    G->D.seconds = G->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - G->t_start).count();
     *decoded = &G->D;
     return CORAL_OK;
 }
 
 // stats: [0] batches, [1] segments whose speculative start was replaced by the exact walk, [2] records fetched for the
-// non-ACGT list, [3] batch capacity (inflated bytes); seconds: [0] total, [1] host-side field handling
-extern "C" int coral_bamgpu_stats(void *handle, int64_t stats[4], double seconds[2]) {
+// non-ACGT list, [3] batch capacity (inflated bytes); seconds: [0] total, [1] host-side field handling (worker thread),
+// [2] file reads of the feeder, [3] pinned buffers / streams set-up, [4] caller waiting for the feeder, [5] caller waiting for the GPU
+extern "C" int coral_bamgpu_stats(void *handle, int64_t stats[4], double seconds[6]) {
     GpuDecoder *G = (GpuDecoder *)handle;
     if (!G || !stats || !seconds) return CORAL_ERR_ARG;
     stats[0] = G->n_batches; stats[1] = G->fixups; stats[2] = G->na_records; stats[3] = (int64_t)G->infl_cap;
-    seconds[0] = G->seconds; seconds[1] = G->host_seconds;
+    seconds[0] = G->seconds; seconds[1] = G->host_seconds; seconds[2] = G->t_read; seconds[3] = G->t_alloc; seconds[4] = G->t_wait_staged;
+    seconds[5] = G->t_wait_gpu;
     return CORAL_OK;
 }
 
@@ -1230,8 +1381,19 @@ extern "C" int coral_bgzf_inflate(const uint8_t *comp, const uint32_t *desc, int
     hipStream_t stream = (hipStream_t)stream_;
     if (n_blocks < 0 || (n_blocks > 0 && (!comp || !desc || !out || !status))) return CORAL_ERR_ARG;
     if (n_blocks == 0) return CORAL_OK;
-    hipLaunchKernelGGL(k_bgzf_inflate, dim3((n_blocks + INFL_WAVES - 1) / INFL_WAVES), dim3(INFL_WAVES * WAVE), 0, stream, comp, (const BlockDesc *)desc,
-                       n_blocks, out, status);
+    const dim3 grid((n_blocks + INFL_WAVES - 1) / INFL_WAVES), block(INFL_WAVES * WAVE);
+    const char *ab = getenv("CORAL_INFLATE_ABLATE");            // timing experiments (tools/bench_inflate.py): wrong output by design
+    const int mode = ab ? atoi(ab) : 0;
+#define CORAL_INFL_LAUNCH(M) hipLaunchKernelGGL(k_bgzf_inflate<M>, grid, block, 0, stream, comp, (const BlockDesc *)desc, n_blocks, out, status)
+    switch (mode) {
+        case 0: CORAL_INFL_LAUNCH(0); break;
+        case 1: CORAL_INFL_LAUNCH(1); break;
+        case 2: CORAL_INFL_LAUNCH(2); break;
+        case 4: CORAL_INFL_LAUNCH(4); break;
+        case 12: CORAL_INFL_LAUNCH(12); break;
+        case 13: CORAL_INFL_LAUNCH(13); break;
+        default: set_error("CORAL_INFLATE_ABLATE: unknown mode"); return CORAL_ERR_ARG;
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("k_bgzf_inflate: ") + hipGetErrorString(e)); return CORAL_ERR_HIP; }
     return CORAL_OK;

@@ -17,7 +17,7 @@
 
 #if defined(__HIPCC__)
 #define CORAL_HD __host__ __device__ __forceinline__
-#define CORAL_NOUNROLL _Pragma("nounroll")
+#define CORAL_NOUNROLL _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
 #else
 #define CORAL_HD inline
 #define CORAL_NOUNROLL
@@ -29,8 +29,9 @@ enum { LL_BITS = 10, D_BITS = 8, WAVE_LANES = 64 };
 enum { OK = 0, ERR_BTYPE = 1, ERR_STORED = 2, ERR_CODELENS = 3, ERR_OVERSUBSCRIBED = 4, ERR_BAD_CODE = 5, ERR_DISTANCE = 6,
        ERR_OVERFLOW = 7, ERR_INPUT = 8, ERR_SHORT = 9 };
 
-// Literal / length table entry (16 bits):  bits 0..3 code length (0 = not in the primary table: a longer code or an unused
-// pattern), bit 4 = "not a literal", bits 5..7 extra bits of a length code (7 = end of block), bits 8..15 the literal byte or
+// Literal / length table entry (16 bits):  bits 0..3 code length (0 = not in the primary table: a longer code, an unused
+// pattern, or the end-of-block code, which is left to the canonical decode: once per block), bit 4 = "not a literal",
+// bits 5..7 extra bits of a length code (7 = end of block, only out of ll_entry), bits 8..15 the literal byte or
 // (length base - 3).  A literal is recognised by ONE bit test; a long / unused pattern is 0x0010.
 // Distance table entry (32 bits):  bits 0..3 code length (0 as above), bits 8..11 extra bits, bits 16..31 distance base.
 enum { LL_NOT_LITERAL = 16, LL_EOB_EXTRA = 7, LL_LONG = 0x0010 };
@@ -102,7 +103,7 @@ struct Inflater {
         }
     }
     CORAL_HD uint32_t bits(int n) {              // n <= 32 and n <= bc
-        const uint32_t v = (uint32_t)(bb & ((1ull << n) - 1ull));
+        const uint32_t v = n >= 32 ? (uint32_t)bb : ((uint32_t)bb & ~(~0u << n));
         bb >>= n;
         bc -= n;
         return v;
@@ -146,7 +147,7 @@ struct Inflater {
                     const uint32_t cnt = count[l];
                     if (code - first < cnt) {                     // (unsigned: code >= first always holds here)
                         const uint32_t s = sym[index + (code - first)];
-                        entry = is_dist ? dist_entry(s, (uint32_t)l) : ll_entry(s, (uint32_t)l);
+                        entry = is_dist ? dist_entry(s, (uint32_t)l) : (s == 256 ? (uint32_t)LL_LONG : ll_entry(s, (uint32_t)l));
                         break;
                     }
                     index += cnt;
@@ -301,80 +302,84 @@ struct Inflater {
         return OK;
     }
 
-    // The symbol loop the device uses (W::paired_literals), scheduled for the scalar pipe of a CU: a literal is ONE bit test on
-    // a 16-bit table entry; after a refill check (more than 32 bits) two table symbols are decoded back to back; the output
-    // capacity is not tested per literal — the backend drops excess output (clamp) and raises `over`, which is looked at
-    // once per pair.  The rare paths (codes longer than the table, bad codes) are loops, so the hot loop stays small.
-    // Needs from the backend, in addition: vec(x) (identity; keeps index arithmetic on the vector pipe), `over`, clamp().
-    CORAL_HD int codes_paired() {
+    // The symbol loop the device uses (W::vector_loop).  A CU issues one scalar and (over its four SIMDs) one vector instruction
+    // per cycle, and symbol decoding is scalar by nature — so everything that does not feed a branch runs on the vector pipe,
+    // redundantly in all lanes: table index, field extraction (code length, extra bits, base), ring addresses.  Scalar work per
+    // symbol is the bit-buffer shift, the position and the branch conditions.  Two table symbols are decoded per refill check;
+    // nothing in the hot path tests for errors: the backend clamps bad lengths / distances, collects them (`bad()`), bounds the
+    // output (`over`, looked at once per round), and the canonical loop handles codes longer than the table, unused patterns
+    // and the end of the block.  Values named *v live in vector registers on the device (plain integers on the host).
+    // Needs from the backend: vec(x), bfe(x, offset, width), lit(bytev), match(lenv, distv), needs_attention() / attention()
+    // (one compare per round: output to be written back, or the backend wants the loop to stop), bad().
+    CORAL_HD int codes_vector() {
         const uint16_t *ll = T->ll;
         const uint32_t *dt = T->dt;
-        uint32_t ev = 0;                                              // the entry as loaded (a vector register on the device)
         for (;;) {
+            if (w.needs_attention() && !w.attention()) return ERR_OVERFLOW;      // a line of output is complete, or `over`
             need();                                                   // more than 32 bits
-            ev = ll[w.vec((uint32_t)bb) & ((1u << LL_BITS) - 1u)];
+            uint32_t bbv = w.vec((uint32_t)bb);
+            uint32_t ev = ll[bbv & ((1u << LL_BITS) - 1u)];
             uint32_t e = w.uni(ev);
             if (!(e & LL_NOT_LITERAL)) {
                 const uint32_t nb1 = e & 15u;
                 bb >>= nb1;
                 bc -= (int)nb1;
-                w.put_literal(ev >> 8);
-                ev = ll[w.vec((uint32_t)bb) & ((1u << LL_BITS) - 1u)];     // at least 23 bits left: enough for any table entry
+                w.lit(ev >> 8);
+                bbv = w.vec((uint32_t)bb);                            // at least 23 bits left: enough for any table entry
+                ev = ll[bbv & ((1u << LL_BITS) - 1u)];
                 e = w.uni(ev);
                 if (!(e & LL_NOT_LITERAL)) {
                     const uint32_t nb2 = e & 15u;
                     bb >>= nb2;
                     bc -= (int)nb2;
-                    w.put_literal(ev >> 8);
-                    if (w.over) return ERR_OVERFLOW;
+                    w.lit(ev >> 8);
                     continue;
                 }
             }
-            // a length, the end of the block, or a code that is not in the table (at least 23 bits in the buffer)
-            uint32_t nb = e & 15u;
-            if (nb == 0) {
-                const int s = decode_long(T->ll_count, T->ll_sym);    // up to 15 bits
+            uint32_t lenv;
+            if ((e & 15u) == 0) {                                     // not in the table: canonical decode (up to 15 of >= 23 bits)
+                const int s = decode_long(T->ll_count, T->ll_sym);
                 if (s < 0) return ERR_BAD_CODE;
-                e = ll_entry((uint32_t)s, 1);
-                if (e == LL_LONG) return ERR_BAD_CODE;
-                if (!(e & LL_NOT_LITERAL)) {
-                    w.put_literal(e >> 8);
-                    if (w.over) return ERR_OVERFLOW;
+                if (s < 256) {
+                    w.lit((uint32_t)s);
                     continue;
                 }
-            } else {
-                bb >>= nb;
-                bc -= (int)nb;
+                if (s == 256) return w.bad() ? ERR_DISTANCE : OK;
+                const uint32_t x = ll_entry((uint32_t)s, 1);         // (a length of 1 tells a length-3 code from LL_LONG)
+                if (x == LL_LONG) return ERR_BAD_CODE;
+                lenv = 3u + (x >> 8) + bits((int)((x >> 5) & 7u));
+            } else {                                                  // a length: code + extra bits leave the buffer in one shift
+                const uint32_t nbv = ev & 15u, xbv = (ev >> 5) & 7u;
+                lenv = 3u + (ev >> 8) + w.bfe(bbv, nbv, xbv);
+                const uint32_t tot = w.uni(nbv + xbv);                // <= 10 + 5
+                bb >>= tot;
+                bc -= (int)tot;
             }
-            const uint32_t xb = (e >> 5) & 7u;
-            if (xb == LL_EOB_EXTRA) {
-                w.clamp();
-                return w.over ? ERR_OVERFLOW : OK;
-            }
-            const int len = (int)(3u + (e >> 8) + bits((int)xb));      // up to 5 more bits: 15 + 5 <= 23
             need();
-            uint32_t d = w.uni(dt[(uint32_t)bb & ((1u << D_BITS) - 1u)]);
-            nb = d & 15u;
-            if (nb == 0) {
+            bbv = w.vec((uint32_t)bb);
+            const uint32_t dv = dt[bbv & ((1u << D_BITS) - 1u)];
+            const uint32_t d = w.uni(dv);
+            uint32_t distv;
+            if ((d & 15u) == 0) {
                 const int s = decode_long(T->d_count, T->ll_sym + 288);
                 if (s < 0) return ERR_BAD_CODE;
-                d = dist_entry((uint32_t)s, 1);
-                if (d == 0) return ERR_BAD_CODE;
+                const uint32_t x = dist_entry((uint32_t)s, 1);
+                if (x == 0) return ERR_BAD_CODE;
+                distv = (x >> 16) + bits((int)((x >> 8) & 15u));
             } else {
-                bb >>= nb;
-                bc -= (int)nb;
+                const uint32_t nbv = dv & 15u, xbv = (dv >> 8) & 15u;
+                distv = (dv >> 16) + w.bfe(bbv, nbv, xbv);            // <= 15 + 13 of the 32 low bits
+                const uint32_t tot = w.uni(nbv + xbv);
+                bb >>= tot;
+                bc -= (int)tot;
             }
-            const uint32_t dxb = (d >> 8) & 15u;
-            const int dist = (int)((d >> 16) + bits((int)dxb));       // 15 + 13 <= 32
-            if (w.over || w.produced() + len > w.capacity()) return ERR_OVERFLOW;
-            if (!w.copy_match(len, dist)) return ERR_DISTANCE;
-            if (w.input_exhausted()) return ERR_INPUT;
+            w.match(lenv, distv);
         }
     }
 
     // The plain symbol loop (one symbol per round, capacity tested per literal).
     CORAL_HD int codes() {
-        if constexpr (W::paired_literals) return codes_paired();
+        if constexpr (W::vector_loop) return codes_vector();
         const uint16_t *ll = T->ll;
         const uint32_t *dt = T->dt;
         for (;;) {

@@ -351,7 +351,8 @@ const char *coral_bam_last_error(void);
  *   host   the host-side half of the result as a handle for coral_bam_decode_sizes / _fill / _stats (cigar: pass NULL,
  *          n_cigar_words is 0; cigar_off covers the whole decoded range); owned by the decoder, do not close it
  *   stats  stats = batches, segments whose speculative record start was replaced by the exact walk, records fetched
- *          whole for the non-ACGT list, batch capacity; seconds = total wall time, host-side field handling
+ *          whole for the non-ACGT list, batch capacity; seconds = total wall time, host-side field handling, file reads,
+ *          set-up of pinned buffers and streams, time the caller waited for the file feeder, ... for the GPU
  * coral_bgzf_inflate: one inflate launch over caller-provided device buffers — desc = n_blocks x {src_off, src_len,
  * dst_off, isize} uint32 (raw DEFLATE streams in `comp`, which must be readable 4096 bytes beyond the last stream);
  * status[b] = 0 or the decoder's error code.
@@ -362,7 +363,7 @@ int coral_bamgpu_start(void *handle, void *workspace, int64_t workspace_bytes);
 int coral_bamgpu_next(void *handle, int64_t out[4], void *stream);
 int coral_bamgpu_emit(void *handle, uint32_t *cigar_dst, int64_t *cigar_off_dst, void *stream);
 int coral_bamgpu_host(void *handle, void **decoded);
-int coral_bamgpu_stats(void *handle, int64_t stats[4], double seconds[2]);
+int coral_bamgpu_stats(void *handle, int64_t stats[4], double seconds[6]);
 int coral_bamgpu_close(void *handle);
 int coral_bgzf_inflate(const uint8_t *comp, const uint32_t *desc, int32_t n_blocks, uint8_t *out, int32_t *status,
                        void *stream);

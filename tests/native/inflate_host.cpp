@@ -7,9 +7,9 @@
 
 using namespace coral_inflate;
 
-template <bool PAIRED>
+template <bool VECTOR>
 struct HostWaveT {
-    static constexpr bool paired_literals = PAIRED;
+    static constexpr bool vector_loop = VECTOR;
     const uint8_t *src;
     long long src_len;
     uint8_t *out;
@@ -27,14 +27,26 @@ struct HostWaveT {
         return v;
     }
     bool input_exhausted() const { return win0 + 4 * pulled > src_len + 8; }
-    // paired loop: output beyond the capacity is dropped and flagged, as the device backend does (its ring absorbs it)
-    bool over = false;
+    // the vector loop's backend operations, with the device backend's error behaviour: nothing is tested per symbol — a bad
+    // length / distance is clamped and remembered, output beyond the capacity is dropped and raises `over`
+    bool over = false, bad_ = false;
     uint32_t vec(uint32_t x) const { return x; }
-    void clamp() {}
-    void put_literal(uint32_t b) {
+    uint32_t bfe(uint32_t x, uint32_t off, uint32_t width) const { return width ? (x >> off) & (~0u >> (32 - width)) : 0u; }
+    bool bad() const { return bad_; }
+    bool needs_attention() const { return over; }
+    bool attention() { return !over; }
+    void lit(uint32_t b) {
         if (o >= cap) { over = true; return; }
         out[o++] = (uint8_t)b;
     }
+    void match(uint32_t len, uint32_t dist) {
+        if (dist > (uint32_t)o) { bad_ = true; return; }
+        if ((int)len > cap - o) { over = true; len = (uint32_t)(cap - o); }
+        for (uint32_t k = 0; k < len; ++k) out[o + k] = out[o + k - dist];
+        o += (int)len;
+        if (input_exhausted()) over = true;
+    }
+    void put_literal(uint32_t b) { lit(b); }
     bool copy_match(int len, int dist) {
         if (dist > o) return false;
         for (int k = 0; k < len; ++k) out[o + k] = out[o + k - dist];
@@ -59,18 +71,19 @@ struct HostWaveT {
     void fence() {}
 };
 
-template <bool PAIRED>
+template <bool VECTOR>
 static int run(const uint8_t *src, long long n, uint8_t *out, int cap, int *produced) {
     static Tables T;
-    HostWaveT<PAIRED> w;
+    HostWaveT<VECTOR> w;
     w.src = src; w.src_len = n; w.out = out; w.cap = cap;
-    Inflater<HostWaveT<PAIRED>> inf(w, &T);
-    const int rc = inf.run();
+    Inflater<HostWaveT<VECTOR>> inf(w, &T);
+    int rc = inf.run();
+    if (rc == OK && (w.over || w.bad_)) rc = ERR_OVERFLOW;
     *produced = w.o;
     return rc;
 }
 
-// paired = 1: the symbol loop the device runs (Inflater::codes_paired); 0: the plain loop
+// paired = 1: the symbol loop the device runs (Inflater::codes_vector); 0: the plain loop
 extern "C" int coral_test_inflate(const uint8_t *src, long long n, uint8_t *out, int cap, int *produced, int paired) {
     return paired ? run<true>(src, n, out, cap, produced) : run<false>(src, n, out, cap, produced);
 }

@@ -49,6 +49,13 @@ def test_core_equals_zlib(inflate):
                 assert inflate(comp, len(data)) == (0, data), (len(data), level, strat)
 
 
+def test_core_on_the_gpu_test_streams(inflate):
+    """The very streams the inflate kernel is checked on (tests/test_bam_gpu.py)."""
+    from tests.deflate_streams import streams
+    for comp, data in streams():
+        assert inflate(comp, len(data)) == (0, data)
+
+
 def test_core_multi_block_streams(inflate):
     rnd = random.Random(2)
     for _ in range(40):

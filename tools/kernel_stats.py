@@ -19,7 +19,7 @@ with open(out_md, "w") as fp:
     fp.write("The run also contains the synthetic-data generator and hipcub/rocprim sorts: %d kernel rows, %.1f ms in total.\n" % (len(rows), total))
     fp.write("Kernels of libcoral_hip.so:\n\n| kernel | calls | total ms | avg ms | min ms | max ms |\n|---|---|---|---|---|---|\n")
     for r in sorted(ours, key=lambda r: -float(r["TotalDurationNs"])):
-        fp.write("| `%s` | %s | %.3f | %.3f | %.3f | %.3f |\n" % (r["Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", ""), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+        fp.write("| `%s` | %s | %.3f | %.3f | %.3f | %.3f |\n" % (r["Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", ""), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                               float(r["AverageNs"]) / 1e6, float(r["MinNs"]) / 1e6, float(r["MaxNs"]) / 1e6))
     scan = [r for r in ours if "k_cigar_scan" in r["Name"]]
     if scan:
