@@ -57,6 +57,14 @@ def decode_bam(path: str, n_threads: Optional[int] = None, rank: int = 0, world:
         L.coral_bam_decode_close(h)
 
 
+def load_bam(path: str, device="cuda:0", n_threads: Optional[int] = None, rank: int = 0, world: int = 1) -> Records:
+    """The product's way from a BAM file to records: inflate and parse on the GPU (``decode_bam_gpu``) when ``device`` is one;
+    ``CORAL_BAM_DECODE=cpu`` selects the host pipeline (``decode_bam``: same result, CIGAR words in host memory)."""
+    if torch.device(device).type == "cuda" and os.environ.get("CORAL_BAM_DECODE", "gpu") != "cpu":
+        return decode_bam_gpu(path, device, n_threads=n_threads, rank=rank, world=world)
+    return decode_bam(path, n_threads=n_threads, rank=rank, world=world)
+
+
 def _records_from_handle(L, h, cigar, cigar_words: int) -> Records:
     """Fill a Records object from a decode handle (coral_bam_decode_sizes / _fill).  ``cigar`` None: the handle holds the op
     words (CPU pipeline); a tensor: the ops are already on the device (GPU pipeline) and the handle holds everything else."""

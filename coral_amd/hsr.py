@@ -241,9 +241,9 @@ def locate_hsrs(args, records=None, device="cuda:0"):
     cns = _copy_numbers(args.cn_seg)
 
     if records is None:
-        from .bam import decode_bam
+        from .bam import load_bam
         from .records import DeviceRecords
-        records = DeviceRecords(decode_bam(args.lr_bam), getattr(args, "device", device))
+        records = DeviceRecords(load_bam(args.lr_bam, getattr(args, "device", device)), getattr(args, "device", device))
     dr = records
     T = build_chimeric_table(dr)                              # whole-BAM fetch (hsr.py:21-51) through coral_sa_table
     print("Fetched %d chimeric alignments." % T.n_reads)

@@ -263,9 +263,9 @@ class bam_to_breakpoint_nanopore():
 
     def __init__(self, lr_bamfile, seedfile, records=None, device="cuda:0"):
         if records is None:
-            from .bam import decode_bam
+            from .bam import load_bam
             from .records import DeviceRecords
-            records = DeviceRecords(decode_bam(lr_bamfile), device)
+            records = DeviceRecords(load_bam(lr_bamfile, device), device)
         self.rec = records
         self.lr_bamfh = _RecordsFile(records)
         self.lr_graph = []
@@ -1558,9 +1558,9 @@ def reconstruct_graph(args):
     for arg in sys.argv:
         commandstring += ('"{}" '.format(arg) if ' ' in arg else "{} ".format(arg))
     logging.info(_t() + commandstring)
-    from .bam import decode_bam
+    from .bam import load_bam
     from .records import DeviceRecords
-    records = DeviceRecords(decode_bam(args.lr_bam), getattr(args, "device", "cuda:0"))
+    records = DeviceRecords(load_bam(args.lr_bam, getattr(args, "device", "cuda:0")), getattr(args, "device", "cuda:0"))
     return build_graph_from_records(records, args.cnv_seed, args.cn_seg, args.output_prefix, args.min_bp_support,
                                     args.output_bp, gc_policy=getattr(args, "gc_policy", "pause"))
 

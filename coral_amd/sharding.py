@@ -159,7 +159,7 @@ def load_bam_sharded(path: str, rank: int, world: int, device, group=None, n_thr
     import io
     from . import bam
     from .records import DeviceRecords, HostMirrors
-    rec = bam.decode_bam(path, n_threads=n_threads, rank=rank, world=world)
+    rec = bam.load_bam(path, device, n_threads=n_threads, rank=rank, world=world)
     stats = dict(bam.LAST_DECODE)
     if world == 1:
         dr = DeviceRecords(rec, device)
