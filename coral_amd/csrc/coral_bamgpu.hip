@@ -181,7 +181,7 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
             a += len;
             return;
         }
-        if (dist <= RING_BYTES - 64 || (ABLATE & 2)) {
+        if (__builtin_expect(dist <= RING_BYTES - 64 || (ABLATE & 2), 1)) {
             // byte k of the match = byte (k mod dist) of the dist bytes in front of it (k mod dist = k when dist >= 64 > lane)
             const float rd = __builtin_amdgcn_rcpf((float)distv);
             auto copy = [&](uint32_t k, float kh) {
@@ -190,7 +190,7 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
                 if (k < lenv) *ring_at(av + k) = *ring_at(av - distv + km);
             };
             copy((uint32_t)lane, lane_half);
-            if (len > WAVE) {                                         // chunks in order: LDS operations of a wave execute in order
+            if (__builtin_expect(len > WAVE, 0)) {                    // chunks in order: LDS operations of a wave execute in order
 _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
                 for (int k = lane + WAVE; k < len; k += WAVE) copy((uint32_t)k, (float)k + 0.5f);
             }

@@ -15,6 +15,8 @@
 #pragma once
 #include <stdint.h>
 
+#define CORAL_LIKELY(x) __builtin_expect(!!(x), 1)
+#define CORAL_UNLIKELY(x) __builtin_expect(!!(x), 0)
 #if defined(__HIPCC__)
 #define CORAL_HD __host__ __device__ __forceinline__
 #define CORAL_NOUNROLL _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
@@ -315,7 +317,7 @@ struct Inflater {
         const uint16_t *ll = T->ll;
         const uint32_t *dt = T->dt;
         for (;;) {
-            if (w.needs_attention() && !w.attention()) return ERR_OVERFLOW;      // a line of output is complete, or `over`
+            if (CORAL_UNLIKELY(w.needs_attention()) && !w.attention()) return ERR_OVERFLOW;      // a line of output is complete, or `over`
             need();                                                   // more than 32 bits
             uint32_t bbv = w.vec((uint32_t)bb);
             uint32_t ev = ll[bbv & ((1u << LL_BITS) - 1u)];
@@ -337,7 +339,7 @@ struct Inflater {
                 }
             }
             uint32_t lenv;
-            if ((e & 15u) == 0) {                                     // not in the table: canonical decode (up to 15 of >= 23 bits)
+            if (CORAL_UNLIKELY((e & 15u) == 0)) {                     // not in the table: canonical decode (up to 15 of >= 23 bits)
                 const int s = decode_long(T->ll_count, T->ll_sym);
                 if (s < 0) return ERR_BAD_CODE;
                 if (s < 256) {
@@ -360,7 +362,7 @@ struct Inflater {
             const uint32_t dv = dt[bbv & ((1u << D_BITS) - 1u)];
             const uint32_t d = w.uni(dv);
             uint32_t distv;
-            if ((d & 15u) == 0) {
+            if (CORAL_UNLIKELY((d & 15u) == 0)) {
                 const int s = decode_long(T->d_count, T->ll_sym + 288);
                 if (s < 0) return ERR_BAD_CODE;
                 const uint32_t x = dist_entry((uint32_t)s, 1);
