@@ -77,9 +77,8 @@ struct DevWaveT {
     int base_dw;                // dword index (from in_base) the Inflater's `dwords` counts from
     int win;                    // dword index of lane 0 of r0
     int last_dw;                // dword index of the stream's last byte
-    int pulled, pull_limit;     // dwords handed out; more than the limit = the stream is corrupt
-    uint32_t r0, r1;            // lane i: dwords win + i and win + 64 + i of the input
-    int idx;                    // next dword of the 128 (0..63: r0, 64..127: r1)
+    uint32_t r0, r1;            // lane i: dwords win + i (being consumed) and win + 64 + i (loaded ahead) of the input
+    int idx;                    // next dword of r0 (0..63)
     uint8_t *gbase;             // out - (out & 255)
     uint8_t *ring;              // LDS, RING_BYTES
     int a0, aend;               // aligned coordinates of the block's first byte and of the byte behind its last
@@ -88,7 +87,8 @@ struct DevWaveT {
     int attend;                 // the symbol loop calls attention() once `a` has reached this: a 256-byte line is complete (or,
                                 // set to a - 1 by the rare paths, `over` was raised)
     uint32_t badv;              // (vector) a distance reached in front of the output
-    bool over;                  // more output than the block may have, or more input than the stream holds: stop
+    bool over;                  // more output than the block may have, more input than the stream holds, or fail(): stop
+    int err;                    // the first fail() code
 
     __device__ __forceinline__ uint32_t uni(uint32_t x) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
     __device__ __forceinline__ uint32_t vec(uint32_t x) const {      // keeps what is computed from x on the vector pipe
@@ -97,6 +97,13 @@ struct DevWaveT {
     }
     __device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t off, uint32_t width) const { return __builtin_amdgcn_ubfe(x, off, width); }
     __device__ __forceinline__ bool bad() const { return uni(badv) != 0u; }
+    __device__ __forceinline__ void fail(int code) {                 // stop the symbol loop at its next round
+        if (!err) err = code;
+        over = true;
+        attend = a - 1;
+    }
+    __device__ __forceinline__ bool failed() const { return over || err != 0 || bad(); }
+    __device__ __forceinline__ int error_code() const { return err ? err : bad() ? (int)coral_inflate::ERR_DISTANCE : (int)coral_inflate::ERR_OVERFLOW; }
     __device__ __forceinline__ bool needs_attention() const { return a >= attend; }
     // Input window loads never start behind the stream's last dword: a corrupt stream that keeps asking for input re-reads the
     // end (and is stopped by the pull limit) instead of walking out of the compressed buffer (readable COMP_SLACK bytes beyond
@@ -110,26 +117,20 @@ struct DevWaveT {
         r1 = input_load(win + WAVE);
         idx = 0;
     }
+    // The next 32 input bits: one v_readlane; every 64th call moves on to the register loaded 64 dwords ago and starts the
+    // load of its successor.
     __device__ __forceinline__ uint32_t next_dword() {
-        uint32_t v;
-        if (++pulled > pull_limit) {
-            over = true;
-            attend = a - 1;
-        }
-        if (idx < WAVE) {
-            v = (uint32_t)__builtin_amdgcn_readlane((int)r0, idx);
-            if (++idx == WAVE) r0 = input_load(win + 2 * WAVE);     // r0 is used up: refill it for the turn after r1's
-        } else {
-            v = (uint32_t)__builtin_amdgcn_readlane((int)r1, idx - WAVE);
-            if (++idx == 2 * WAVE) {                                // r1 is used up
-                win += 2 * WAVE;
-                r1 = input_load(win + WAVE);
-                idx = 0;
-            }
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)r0, idx);
+        if (__builtin_expect(++idx == WAVE, 0)) {
+            win += WAVE;
+            r0 = r1;
+            r1 = input_load(win + WAVE);
+            idx = 0;
+            if (win > last_dw + WAVE) fail(coral_inflate::ERR_INPUT);    // a whole window behind the stream's end: corrupt
         }
         return v;
     }
-    __device__ __forceinline__ bool input_exhausted() const { return pulled > pull_limit; }
+    __device__ __forceinline__ bool input_exhausted() const { return win + idx > last_dw + 4; }
     __device__ __forceinline__ uint8_t *ring_at(uint32_t av) const { return ring + (av & RING_MASK); }
     // completed 256-byte lines ring -> global memory (the block's first line may start inside a line: byte stores there);
     // never beyond the block's last byte
@@ -225,7 +226,6 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
         const int byte = 4 * (base_dw + dwords) + (int)n;
         base_dw = byte >> 2;
         win = base_dw;
-        pulled = base_dw;
         load_window();
         return (uint32_t)(byte & 3) * 8u;
     }
@@ -267,8 +267,6 @@ __global__ __launch_bounds__(INFL_WAVES *WAVE) void k_bgzf_inflate(const uint8_t
     w.base_dw = 0;
     w.win = 0;
     w.last_dw = (int)((mis + d.src_len) >> 2);
-    w.pulled = 0;
-    w.pull_limit = w.last_dw + 5;
     w.a0 = (int)(((uintptr_t)out + d.dst_off) & 255u);
     w.aend = w.a0 + (int)d.isize;
     w.gbase = out + ((long long)d.dst_off - w.a0);
@@ -277,11 +275,12 @@ __global__ __launch_bounds__(INFL_WAVES *WAVE) void k_bgzf_inflate(const uint8_t
     w.attend = (w.a0 | 255) + 1;
     w.badv = 0;
     w.over = false;
+    w.err = 0;
     w.load_window();
     coral_inflate::Inflater<DevWaveT<ABLATE>> inf(w, &tables[wib]);
     int rc = inf.run((int)mis * 8);
     w.finish();
-    if (rc == coral_inflate::OK && (w.over || w.bad())) rc = coral_inflate::ERR_OVERFLOW;
+    if (rc == coral_inflate::OK && w.failed()) rc = w.error_code();
     if (lane == 0) status[b] = rc;
 }
 

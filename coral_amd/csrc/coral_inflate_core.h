@@ -312,12 +312,14 @@ struct Inflater {
     // output (`over`, looked at once per round), and the canonical loop handles codes longer than the table, unused patterns
     // and the end of the block.  Values named *v live in vector registers on the device (plain integers on the host).
     // Needs from the backend: vec(x), bfe(x, offset, width), lit(bytev), match(lenv, distv), needs_attention() / attention()
-    // (one compare per round: output to be written back, or the backend wants the loop to stop), bad().
+    // (one compare per round: output to be written back, or the loop is to stop), fail(code) / failed() / error_code().
     CORAL_HD int codes_vector() {
         const uint16_t *ll = T->ll;
         const uint32_t *dt = T->dt;
+        // ONE way out besides the end-of-block code: every rare problem raises the backend's flag (fail), and the round's
+        // single check sees it — several `return`s inside the loop cost a scalar state machine in every round
         for (;;) {
-            if (CORAL_UNLIKELY(w.needs_attention()) && !w.attention()) return ERR_OVERFLOW;      // a line of output is complete, or `over`
+            if (CORAL_UNLIKELY(w.needs_attention()) && !w.attention()) break;      // a line of output is complete, or stop
             need();                                                   // more than 32 bits
             uint32_t bbv = w.vec((uint32_t)bb);
             uint32_t ev = ll[bbv & ((1u << LL_BITS) - 1u)];
@@ -341,14 +343,16 @@ struct Inflater {
             uint32_t lenv;
             if (CORAL_UNLIKELY((e & 15u) == 0)) {                     // not in the table: canonical decode (up to 15 of >= 23 bits)
                 const int s = decode_long(T->ll_count, T->ll_sym);
-                if (s < 0) return ERR_BAD_CODE;
-                if (s < 256) {
+                if (s == 256) return w.failed() ? w.error_code() : OK;
+                const uint32_t x = s < 0 ? (uint32_t)LL_LONG : ll_entry((uint32_t)s, 1);     // (a length of 1 tells a length-3 code from LL_LONG)
+                if (s >= 0 && s < 256) {
                     w.lit((uint32_t)s);
                     continue;
                 }
-                if (s == 256) return w.bad() ? ERR_DISTANCE : OK;
-                const uint32_t x = ll_entry((uint32_t)s, 1);         // (a length of 1 tells a length-3 code from LL_LONG)
-                if (x == LL_LONG) return ERR_BAD_CODE;
+                if (x == LL_LONG) {
+                    w.fail(ERR_BAD_CODE);
+                    continue;
+                }
                 lenv = 3u + (x >> 8) + bits((int)((x >> 5) & 7u));
             } else {                                                  // a length: code + extra bits leave the buffer in one shift
                 const uint32_t nbv = ev & 15u, xbv = (ev >> 5) & 7u;
@@ -364,9 +368,11 @@ struct Inflater {
             uint32_t distv;
             if (CORAL_UNLIKELY((d & 15u) == 0)) {
                 const int s = decode_long(T->d_count, T->ll_sym + 288);
-                if (s < 0) return ERR_BAD_CODE;
-                const uint32_t x = dist_entry((uint32_t)s, 1);
-                if (x == 0) return ERR_BAD_CODE;
+                const uint32_t x = s < 0 ? 0u : dist_entry((uint32_t)s, 1);
+                if (x == 0) {
+                    w.fail(ERR_BAD_CODE);
+                    continue;
+                }
                 distv = (x >> 16) + bits((int)((x >> 8) & 15u));
             } else {
                 const uint32_t nbv = dv & 15u, xbv = (dv >> 8) & 15u;
@@ -377,6 +383,7 @@ struct Inflater {
             }
             w.match(lenv, distv);
         }
+        return w.error_code();
     }
 
     // The plain symbol loop (one symbol per round, capacity tested per literal).

@@ -32,9 +32,12 @@ struct HostWaveT {
     bool over = false, bad_ = false;
     uint32_t vec(uint32_t x) const { return x; }
     uint32_t bfe(uint32_t x, uint32_t off, uint32_t width) const { return width ? (x >> off) & (~0u >> (32 - width)) : 0u; }
-    bool bad() const { return bad_; }
+    int err_ = 0;
     bool needs_attention() const { return over; }
     bool attention() { return !over; }
+    void fail(int code) { if (!err_) err_ = code; over = true; }
+    bool failed() const { return over || bad_ || err_ != 0; }
+    int error_code() const { return err_ ? err_ : bad_ ? (int)ERR_DISTANCE : (int)ERR_OVERFLOW; }
     void lit(uint32_t b) {
         if (o >= cap) { over = true; return; }
         out[o++] = (uint8_t)b;
@@ -78,7 +81,7 @@ static int run(const uint8_t *src, long long n, uint8_t *out, int cap, int *prod
     w.src = src; w.src_len = n; w.out = out; w.cap = cap;
     Inflater<HostWaveT<VECTOR>> inf(w, &T);
     int rc = inf.run();
-    if (rc == OK && (w.over || w.bad_)) rc = ERR_OVERFLOW;
+    if (rc == OK && w.failed()) rc = w.error_code();
     *produced = w.o;
     return rc;
 }
