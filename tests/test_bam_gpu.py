@@ -135,6 +135,33 @@ def test_gpu_byte_ranges_partition_the_file(config, n_reads, tmp_path):
             assert (list(v) == list(got[k])) if k == "names" else np.array_equal(v, got[k]), (world, k)
 
 
+def test_gpu_decode_small_files(tmp_path):
+    """One record; two records of one read; a file whose records are all tiny (thousands per BGZF block, many per segment of the
+    record-start search) decoded whole and as seven byte ranges of a few blocks each."""
+    M, S = 0, 4
+    one = synth.records_from_alignments([dict(tid=2, pos=77, cigar=[(S, 3), (M, 40)], name="only")])
+    p = str(tmp_path / "one.bam")
+    bam.write_bam(one, p)
+    _same_records(bam.decode_bam_gpu(p), bam.decode_bam(p))
+    two = synth.records_from_alignments([dict(tid=0, pos=5, cigar=[(M, 30), (S, 10)], name="r", sa=[(1, 900, 1, 30, 10, 0, 0, 60, 1)]),
+                                         dict(tid=1, pos=900, cigar=[(S, 30), (M, 10)], name="r", flag=2048, sa=[(0, 6, 0, 0, 30, 0, 10, 60, 0)])])
+    p = str(tmp_path / "two.bam")
+    bam.write_bam(two, p)
+    g = bam.decode_bam_gpu(p)
+    _same_records(g, bam.decode_bam(p))
+    assert g.name_id.tolist() == [0, 0] and g.n_names == 1
+    tiny = synth.records_from_alignments([dict(tid=k % 3, pos=100 + k, cigar=[(M, 20 + k % 7)], name="q%d" % (k // 2), has_seq=k % 5 != 0)
+                                          for k in range(6000)])
+    p = str(tmp_path / "tiny.bam")
+    bam.write_bam(tiny, p)
+    whole = bam.decode_bam(p)
+    _same_records(bam.decode_bam_gpu(p), whole)
+    parts = [bam.decode_bam_gpu(p, rank=r, world=7) for r in range(7)]
+    assert sum(q.n for q in parts) == whole.n
+    for r, q in enumerate(parts):
+        _same_records(q, bam.decode_bam(p, rank=r, world=7))
+
+
 def test_gpu_decode_rejects_corrupt_input(tmp_path):
     from coral_amd._lib import CoralHipError
     junk = tmp_path / "junk.bam"
