@@ -19,9 +19,12 @@ tw = time.perf_counter() - t0
 size = os.path.getsize(p)
 out = {"reads": n, "records": rec.n, "level": level, "bgzf_GB": size / 1e9, "write_s": round(tw, 1)}
 del rec
+import subprocess
+print("BAM written: %.2f GB in %.1f s" % (size / 1e9, tw), flush=True)
 t0 = time.perf_counter()
 c = bam.decode_bam(p)
 tc = time.perf_counter() - t0
+print("host decode: %.2f s" % tc, flush=True)
 out["cpu"] = {"seconds": round(tc, 3), "reads_per_s": n / tc, "threads": bam.LAST_DECODE["threads"], "GB_per_s_inflated": bam.LAST_DECODE["uncompressed_bytes"] / tc / 1e9}
 ref_sum = int(c.cigar.to(torch.int64).sum())
 del c
@@ -37,7 +40,9 @@ for r in range(reps):
     del g
     row = {"seconds": round(tg, 3), "reads_per_s": n / tg, "GB_per_s_inflated": st["uncompressed_bytes"] / tg / 1e9,
            "GB_per_s_compressed": st["compressed_bytes"] / tg / 1e9, "batches": st["batches"], "rewalked_segments": st["rewalked_segments"],
-           "host_seconds": round(st["host_seconds"], 3), "nonacgt_records_fetched": st["nonacgt_records_fetched"], "native_seconds": round(st["seconds"], 3)}
+           "host_seconds": round(st["host_seconds"], 3), "nonacgt_records_fetched": st["nonacgt_records_fetched"], "native_seconds": round(st["seconds"], 3),
+           "read_seconds": round(st["read_seconds"], 3), "setup_seconds": round(st["setup_seconds"], 3),
+           "waited_for_file_seconds": round(st["waited_for_file_seconds"], 3), "waited_for_gpu_seconds": round(st["waited_for_gpu_seconds"], 3)}
     out.setdefault("gpu_runs", []).append(row)
     if best is None or tg < best["seconds"]:
         best = row

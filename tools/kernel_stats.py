@@ -23,7 +23,14 @@ with open(out_md, "w") as fp:
                                                               float(r["AverageNs"]) / 1e6, float(r["MinNs"]) / 1e6, float(r["MaxNs"]) / 1e6))
     scan = [r for r in ours if "k_cigar_scan" in r["Name"]]
     if scan:
-        a = float(scan[0]["AverageNs"]) / 1e6
-        fp.write("\n`%s` average %.3f ms for 16.044 GB => %.2f TB/s under the profiler (bench.py's own HIP-event figure of the same run is in the BENCH line below).\n"
-                 % (scan[0]["Name"].split("(")[0].replace("void ", ""), a, 16.044 / a))
+        # the launches over the full 16.04 GB workload only (the end-to-end leg on the small BAM launches the same kernel on 1/10 of it)
+        dur = []
+        for tf in glob.glob(d + "/**/*_kernel_trace.csv", recursive=True):
+            for r in csv.DictReader(open(tf)):
+                if "k_cigar_scan" in r["Kernel_Name"]:
+                    dur.append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e6)
+        full = [x for x in dur if x >= 0.5 * max(dur)] if dur else [float(scan[0]["AverageNs"]) / 1e6]
+        a = sum(full) / len(full)
+        fp.write("\n`%s`: %d launches over the full workload, average %.3f ms for 16.044 GB => %.2f TB/s under the profiler (bench.py's own HIP-event "
+                 "figure of the same run is in the BENCH line below).\n" % (scan[0]["Name"].split("(")[0].replace("void ", ""), len(full), a, 16.044 / a))
 print(open(out_md).read())
