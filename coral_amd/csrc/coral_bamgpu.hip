@@ -64,7 +64,7 @@ struct BlockDesc {
 // lanes to the same address; a match: ring -> ring, or global -> ring when the source has left the ring); each time the
 // position crosses a 256-byte line, the completed lines go to global memory as one dword store per lane.
 // Input: two registers of 64 dwords each, used alternately (the bit buffer is refilled with v_readlane, never from memory).
-// ABLATE (timing experiments of tools/bench_inflate.py only; 0 in the product): 1 = no stores to global memory, 2 = matches whose
+// ABLATE (timing experiments of tools/bench_inflate.py with a -DCORAL_EXPERIMENTS build only; the product instantiates 0): 1 = no stores to global memory, 2 = matches whose
 // source left the ring read the ring anyway, 4 = no match copy, 8 = no literal write.
 template <int ABLATE>
 struct DevWaveT {
@@ -1381,10 +1381,12 @@ extern "C" int coral_bgzf_inflate(const uint8_t *comp, const uint32_t *desc, int
     if (n_blocks < 0 || (n_blocks > 0 && (!comp || !desc || !out || !status))) return CORAL_ERR_ARG;
     if (n_blocks == 0) return CORAL_OK;
     const dim3 grid((n_blocks + INFL_WAVES - 1) / INFL_WAVES), block(INFL_WAVES * WAVE);
-    const char *ab = getenv("CORAL_INFLATE_ABLATE");            // timing experiments (tools/bench_inflate.py): wrong output by design
-    const int mode = ab ? atoi(ab) : 0;
 #define CORAL_INFL_LAUNCH(M) hipLaunchKernelGGL(k_bgzf_inflate<M>, grid, block, 0, stream, comp, (const BlockDesc *)desc, n_blocks, out, status)
-    switch (mode) {
+#ifdef CORAL_EXPERIMENTS
+    // timing experiments (tools/bench_inflate.py with a -DCORAL_EXPERIMENTS build): variants that skip parts of the work and
+    // produce wrong output by design; not compiled into the product library
+    const char *ab = getenv("CORAL_INFLATE_ABLATE");
+    switch (ab ? atoi(ab) : 0) {
         case 0: CORAL_INFL_LAUNCH(0); break;
         case 1: CORAL_INFL_LAUNCH(1); break;
         case 2: CORAL_INFL_LAUNCH(2); break;
@@ -1393,6 +1395,9 @@ extern "C" int coral_bgzf_inflate(const uint8_t *comp, const uint32_t *desc, int
         case 13: CORAL_INFL_LAUNCH(13); break;
         default: set_error("CORAL_INFLATE_ABLATE: unknown mode"); return CORAL_ERR_ARG;
     }
+#else
+    CORAL_INFL_LAUNCH(0);
+#endif
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("k_bgzf_inflate: ") + hipGetErrorString(e)); return CORAL_ERR_HIP; }
     return CORAL_OK;
