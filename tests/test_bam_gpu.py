@@ -143,6 +143,8 @@ def test_gpu_decode_small_files(tmp_path):
     p = str(tmp_path / "one.bam")
     bam.write_bam(one, p)
     _same_records(bam.decode_bam_gpu(p), bam.decode_bam(p))
+    parts = [bam.decode_bam_gpu(p, rank=r, world=5) for r in range(5)]          # byte ranges without any block of their own
+    assert [q.n for q in parts] == [bam.decode_bam(p, rank=r, world=5).n for r in range(5)] and sum(q.n for q in parts) == 1
     two = synth.records_from_alignments([dict(tid=0, pos=5, cigar=[(M, 30), (S, 10)], name="r", sa=[(1, 900, 1, 30, 10, 0, 0, 60, 1)]),
                                          dict(tid=1, pos=900, cigar=[(S, 30), (M, 10)], name="r", flag=2048, sa=[(0, 6, 0, 0, 30, 0, 10, 60, 0)])])
     p = str(tmp_path / "two.bam")
