@@ -185,7 +185,7 @@ bool decode_file(const char *path, int n_threads, int rank, int world, Decoded &
         top_up(k);
         Chunk &c = *chunks[k];
         wait(c.inflated);
-        if (c.bad) { D.error = "zlib inflate failed (corrupt BGZF block)"; return false; }
+        if (c.bad) { D.error = "zlib inflate failed or CRC32 mismatch (corrupt BGZF block)"; return false; }
         if (carry.size() > HEADROOM) {         // (a record of more than 1 MiB straddles) make room
             c.buf.insert(c.buf.begin(), carry.size() - HEADROOM, 0);
             c.begin = 0;

@@ -423,7 +423,9 @@ inline bool inflate_block(z_stream &zs, const MappedFile &f, const Block &b, uin
     zs.next_out = out;
     zs.avail_out = b.isize;
     const int rc = inflate(&zs, Z_FINISH);
-    return rc == Z_STREAM_END && zs.avail_out == 0;
+    if (rc != Z_STREAM_END || zs.avail_out != 0) return false;
+    // the trailer's CRC-32 of the inflated bytes (what htslib's bgzf_read_block checks; the GPU pipeline does the same)
+    return (uint32_t)crc32(crc32(0L, Z_NULL, 0), out, b.isize) == rd32(f.data + b.off + b.csize - 8);
 }
 
 struct ZStream {

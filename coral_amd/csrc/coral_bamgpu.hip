@@ -27,6 +27,7 @@
 
 #include "../../include/coral_hip.h"
 #include "coral_bam_common.h"
+#include "coral_crc32.h"
 #include "coral_inflate_core.h"
 
 using namespace coral_bam;
@@ -282,6 +283,42 @@ __global__ __launch_bounds__(INFL_WAVES *WAVE) void k_bgzf_inflate(const uint8_t
     w.finish();
     if (rc == coral_inflate::OK && w.failed()) rc = w.error_code();
     if (lane == 0) status[b] = rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_crc: the CRC-32 of every inflated block against the one in its BGZF trailer (what htslib checks in bgzf_read_block)
+// ---------------------------------------------------------------------------------------------
+#define ERR_CRC 100
+// One wave per block: every lane takes a contiguous chunk (a multiple of 4 bytes), computes its remainder byte by byte with a
+// 256-entry table in LDS, shifts it by the number of bytes behind its chunk (multiplication by x^(8 n) mod P, coral_crc32.h)
+// and the wave XORs the 64 results.  A block that inflated cleanly but has another checksum gets status ERR_CRC.
+__global__ __launch_bounds__(256) void k_bgzf_crc(const uint8_t *__restrict__ out, const BlockDesc *__restrict__ desc, const uint32_t *__restrict__ want,
+                                                   int n_blocks, int32_t *__restrict__ status) {
+    __shared__ uint32_t table[256];
+    table[threadIdx.x] = coral_crc::table_entry(threadIdx.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int b = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (b >= n_blocks) return;
+    const uint32_t n = desc[b].isize;
+    if (n == 0 || status[b] != 0) return;
+    const uint8_t *p = out + desc[b].dst_off;
+    const uint32_t per = (((n + 63u) >> 6) + 3u) & ~3u;
+    const uint32_t a = min((uint32_t)lane * per, n), e = min(a + per, n);
+    uint32_t r = 0, k = a;
+    for (; k + 4 <= e; k += 4) {
+        uint32_t w;
+        __builtin_memcpy(&w, p + k, 4);
+        r = table[(r ^ w) & 0xffu] ^ (r >> 8);
+        r = table[(r ^ (w >> 8)) & 0xffu] ^ (r >> 8);
+        r = table[(r ^ (w >> 16)) & 0xffu] ^ (r >> 8);
+        r = table[(r ^ (w >> 24)) & 0xffu] ^ (r >> 8);
+    }
+    for (; k < e; ++k) r = table[(r ^ p[k]) & 0xffu] ^ (r >> 8);
+    uint32_t t = coral_crc::shift(r, n - e);
+    if (lane == 0) t ^= coral_crc::shift(0xffffffffu, n);
+    for (int d = 32; d > 0; d >>= 1) t ^= (uint32_t)__shfl_xor((int)t, d);
+    if (lane == 0 && ~t != want[b]) status[b] = ERR_CRC;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -665,6 +702,7 @@ struct GpuDecoder {
     // device workspace (carved from the caller's allocation)
     uint8_t *d_comp[2] = {nullptr, nullptr}, *d_infl[2] = {nullptr, nullptr};
     BlockDesc *d_desc[2] = {nullptr, nullptr};
+    uint32_t *d_crc[2] = {nullptr, nullptr};
     int32_t *d_status[2] = {nullptr, nullptr};
     long long *d_seg_first = nullptr, *d_seg_land = nullptr, *d_seg_base = nullptr, *d_result = nullptr, *d_rec_start = nullptr;
     int32_t *d_seg_count = nullptr, *d_seg_valid = nullptr, *d_error = nullptr, *d_na_list = nullptr, *d_na_count = nullptr;
@@ -676,7 +714,7 @@ struct GpuDecoder {
     size_t scan_tmp_bytes = 0, names_cap = 0, sa_cap = 0;
     // pinned staging + streams
     uint8_t *h_stage[N_STAGE] = {};
-    BlockDesc *h_desc[2] = {nullptr, nullptr};
+    BlockDesc *h_desc[2] = {nullptr, nullptr};      // (pinned; the blocks' trailer CRCs follow the table in the same buffer)
     hipStream_t s_copy = nullptr, s_infl = nullptr;
     hipEvent_t ev_stage[N_STAGE] = {};
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_infl[2] = {nullptr, nullptr}, ev_parsed[2] = {nullptr, nullptr};
@@ -688,6 +726,7 @@ struct GpuDecoder {
     std::vector<BatchInfo> staged;            // batches whose H2D has been issued
     bool feeder_done = false, stop = false;
     int inflate_launched = 0;                 // batches whose inflate kernel has been enqueued
+    int emitted = 0;                          // batches whose parse has been enqueued completely (ev_parsed recorded)
     std::string feeder_error;
     // walk state
     int k = 0;                                // next batch to parse
@@ -784,6 +823,7 @@ void feeder_main(GpuDecoder *G) {
         G->cv.notify_all();
     };
     std::vector<BlockDesc> desc;
+    std::vector<uint32_t> crcs;
     for (;;) {
         const int slot = kb & 1;
         if (at >= G->f.size || (own_bytes >= 0 && overhang_left == 0)) break;
@@ -800,6 +840,7 @@ void feeder_main(GpuDecoder *G) {
         bi.file_off = at;
         bi.ubase = ubase;
         desc.clear();
+        crcs.clear();
         uint64_t comp = 0, infl = 0;          // bytes of the batch so far
         bool full = false;
         while (!full && at < G->f.size) {
@@ -834,6 +875,7 @@ void feeder_main(GpuDecoder *G) {
                 d.dst_off = (uint32_t)infl;
                 d.isize = b.isize;
                 desc.push_back(d);
+                crcs.push_back(rd32(data + p + b.csize - 8));
                 infl += b.isize;
                 p += b.csize;
                 if (owned) { G->D.compressed_bytes += b.csize; G->D.uncompressed_bytes += b.isize; ++G->D.n_blocks; }
@@ -860,9 +902,21 @@ void feeder_main(GpuDecoder *G) {
         }
         ubase += infl;
         bi.last = at >= G->f.size || (own_bytes >= 0 && overhang_left == 0);
-        // the block table goes through its own pinned buffer (one per batch slot; reused after the slot's inflate, see above)
+        // the block table and the trailer CRCs go through their own pinned buffer (one per batch slot).  The device copies of the
+        // slot are still read by the checksum kernel of batch kb - 2 until that batch has been parsed.
+        if (kb >= 2) {
+            {
+                std::unique_lock<std::mutex> lk(G->m);
+                G->cv.wait(lk, [&] { return G->stop || G->emitted >= kb - 1; });
+                if (G->stop) return;
+            }
+            if (hipEventSynchronize(G->ev_parsed[slot]) != hipSuccess) return fail("hipEventSynchronize failed in the feeder");
+        }
         memcpy(G->h_desc[slot], desc.data(), desc.size() * sizeof(BlockDesc));
+        uint32_t *h_crc = reinterpret_cast<uint32_t *>(G->h_desc[slot] + G->max_blocks);
+        memcpy(h_crc, crcs.data(), crcs.size() * 4);
         if (hipMemcpyAsync(G->d_desc[slot], G->h_desc[slot], desc.size() * sizeof(BlockDesc), hipMemcpyHostToDevice, G->s_copy) != hipSuccess ||
+            hipMemcpyAsync(G->d_crc[slot], h_crc, crcs.size() * 4, hipMemcpyHostToDevice, G->s_copy) != hipSuccess ||
             hipEventRecord(G->ev_h2d[slot], G->s_copy) != hipSuccess)
             return fail("host-to-device copy of a block table failed");
         {
@@ -958,6 +1012,7 @@ bool carve(GpuDecoder *G, void *ws, size_t bytes) {
         G->d_comp[i] = (uint8_t *)take(G->comp_cap + COMP_SLACK);
         G->d_infl[i] = (uint8_t *)take((size_t)CARRY_CAP + G->infl_cap + COMP_SLACK);
         G->d_desc[i] = (BlockDesc *)take(G->max_blocks * sizeof(BlockDesc));
+        G->d_crc[i] = (uint32_t *)take(G->max_blocks * 4);
         G->d_status[i] = (int32_t *)take(G->max_blocks * 4);
     }
     const size_t ns = G->nseg_cap, nr = G->rec_cap + 1;
@@ -1088,7 +1143,7 @@ extern "C" int coral_bamgpu_start(void *handle, void *workspace, int64_t workspa
         if ((e = hipEventCreateWithFlags(&G->ev_stage[i], hipEventDisableTiming)) != hipSuccess) return bad("hipEventCreate", e);
     }
     for (int i = 0; i < 2; ++i) {
-        if ((e = hipHostMalloc((void **)&G->h_desc[i], up256(G->max_blocks * sizeof(BlockDesc)), hipHostMallocDefault)) != hipSuccess) return bad("hipHostMalloc", e);
+        if ((e = hipHostMalloc((void **)&G->h_desc[i], up256(G->max_blocks * (sizeof(BlockDesc) + 4)), hipHostMallocDefault)) != hipSuccess) return bad("hipHostMalloc", e);
         if ((e = hipEventCreateWithFlags(&G->ev_h2d[i], hipEventDisableTiming)) != hipSuccess) return bad("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&G->ev_infl[i], hipEventDisableTiming)) != hipSuccess) return bad("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&G->ev_parsed[i], hipEventDisableTiming)) != hipSuccess) return bad("hipEventCreate", e);
@@ -1142,6 +1197,9 @@ extern "C" int coral_bamgpu_next(void *handle, int64_t out[4], void *stream_) {
     }
     // this batch's inflate must be complete before the parse kernels read its bytes
     if (hipStreamWaitEvent(stream, G->ev_infl[slot], 0) != hipSuccess) { G->error = "hipStreamWaitEvent failed"; return fail(CORAL_ERR_HIP); }
+    // checksums of the inflated blocks (as htslib's bgzf_read_block): a mismatch becomes the block's status
+    hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)((bi.n_blocks + 3) / 4)), dim3(256), 0, stream, buf + CARRY_CAP, G->d_desc[slot], G->d_crc[slot], bi.n_blocks,
+                       G->d_status[slot]);
     const long long data_end = CARRY_CAP + (long long)bi.infl_bytes;
     const long long begin = G->searching ? (long long)CARRY_CAP : std::min(G->known_start, data_end);
     const long long limit = (G->last_rank || !bi.has_limit) ? (1ll << 62) : (long long)CARRY_CAP + bi.limit_rel;
@@ -1173,6 +1231,7 @@ extern "C" int coral_bamgpu_next(void *handle, int64_t out[4], void *stream_) {
         std::vector<int32_t> st((size_t)bi.n_blocks);
         if (hipMemcpy(st.data(), G->d_status[slot], st.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { G->error = "hipMemcpy failed"; return fail(CORAL_ERR_HIP); }
         for (int32_t s : st) if (s != 0) { status_bad = s; break; }
+        if (status_bad == ERR_CRC) { G->error = "CRC32 of an inflated BGZF block differs from the one in its trailer"; return fail(CORAL_ERR_FORMAT); }
         if (status_bad) { G->error = "inflate failed (corrupt BGZF block), code " + std::to_string(status_bad); return fail(CORAL_ERR_FORMAT); }
     }
     if (res[3] == 1) { G->error = "record shorter than its fixed fields"; return fail(CORAL_ERR_FORMAT); }
@@ -1333,6 +1392,11 @@ extern "C" int coral_bamgpu_emit(void *handle, uint32_t *cigar_dst, int64_t *cig
     }
     // this buffer may be inflated into again (batch k + 2) once everything above has run
     if (hipEventRecord(G->ev_parsed[slot], stream) != hipSuccess) return fail(CORAL_ERR_HIP, "hipEventRecord failed");
+    {
+        std::lock_guard<std::mutex> lk(G->m);
+        ++G->emitted;
+    }
+    G->cv.notify_all();
     G->have_cur = false;
     ++G->k;
     if (G->finished) D.seconds = G->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - G->t_start).count();

@@ -339,7 +339,8 @@ const char *coral_bam_last_error(void);
  * out in the padded SoA form of coral_records_t directly in HBM, and only a few hundred bytes per record (fixed fields,
  * read name, SA text) come back for the host-side fields.  Same replacement as coral_bam_decode_*
  * (/root/reference/src/infer_breakpoint_graph.py:65, :140-158), same results (tests/test_bam_gpu.py), same byte-range
- * rule for rank / world.  The library allocates no device memory: the caller provides one workspace.
+ * rule for rank / world.  Every inflated block's CRC-32 is checked against its BGZF trailer (k_bgzf_crc), as htslib does.
+ * The library allocates no device memory: the caller provides one workspace.
  *
  *   open   parse the header, size the batches (`batch_bytes` inflated bytes per batch; 0 = default 1 GiB, never more than
  *          the byte range needs) -> *workspace_bytes the caller must allocate on the current device (256-byte aligned)

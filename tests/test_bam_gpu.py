@@ -183,6 +183,18 @@ def test_gpu_decode_rejects_corrupt_input(tmp_path):
     trunc.write_bytes(bytes(good.read_bytes()[:-5000]))
     with pytest.raises(CoralHipError):
         bam.decode_bam_gpu(str(trunc))
+    # a byte flipped inside a STORED block: the block still inflates, only its CRC-32 tells (both pipelines check it, as htslib does)
+    stored = tmp_path / "stored.bam"
+    bam.write_bam_native(rec, str(stored), level=0)
+    data = bytearray(stored.read_bytes())
+    data[len(data) // 2] ^= 0x40
+    flipped = tmp_path / "flipped.bam"
+    flipped.write_bytes(bytes(data))
+    with pytest.raises(CoralHipError, match="CRC32"):
+        bam.decode_bam_gpu(str(flipped))
+    with pytest.raises(CoralHipError):
+        bam.decode_bam(str(flipped))
+    _same_records(bam.decode_bam_gpu(str(stored)), bam.decode_bam(str(stored)))
     _same_records(bam.decode_bam_gpu(str(good)), bam.decode_bam(str(good)))      # and the decoder is fine afterwards
 
 

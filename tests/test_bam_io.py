@@ -176,3 +176,13 @@ def test_decoder_rejects_garbage(tmp_path):
     trunc.write_bytes(bytes(good.read_bytes()[:-5000]))
     with pytest.raises(CoralHipError):
         bam.decode_bam(str(trunc))
+    # a byte flipped inside a STORED block: the block still inflates, only the trailer's CRC-32 tells
+    stored = tmp_path / "stored.bam"
+    bam.write_bam_native(rec, str(stored), level=0)
+    data = bytearray(stored.read_bytes())
+    data[len(data) // 2] ^= 0x40
+    flipped = tmp_path / "flipped.bam"
+    flipped.write_bytes(bytes(data))
+    with pytest.raises(CoralHipError):
+        bam.decode_bam(str(flipped))
+    assert bam.decode_bam(str(stored)).n == rec.n
