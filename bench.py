@@ -199,7 +199,9 @@ def bam_legs(a, rank, world, dev, work):
     import torch
     import torch.distributed as dist
     from coral_amd import bam, sharding, synth
-    cfg = synth.scaled_config(a.config, min(a.bam_reads, synth.named_config(a.config).n_reads))
+    # N > 1: a larger file (up to 4 x), so that every rank's byte range is still worth a decode and the end-to-end figure
+    # shows what per-rank decode does, not the fixed costs
+    cfg = synth.scaled_config(a.config, min(a.bam_reads * min(world, 4), synth.named_config(a.config).n_reads))
     shared = os.path.join("/tmp", "coral_bench_bam_%s" % os.environ.get("MASTER_PORT", str(os.getpid())))
     path = os.path.join(shared, "input.bam")
     cn, seeds = os.path.join(shared, "cn.bed"), os.path.join(shared, "seeds.bed")
