@@ -5,8 +5,9 @@
 // (tests/test_bam_gpu.py compares the two field by field).  The CPU pipeline tops out at the host's inflate rate (zlib,
 // ~0.3 GB/s per core); here the host only moves compressed bytes:
 //
-//   feeder thread   pread(file) -> pinned staging -> BGZF block table of the batch -> H2D            (copy stream)
+//   feeder thread   pread(file) -> ring of small pinned buffers -> BGZF block table of the batch -> H2D          (copy stream)
 //   k_bgzf_inflate  one wave per BGZF block: DEFLATE decode (coral_inflate_core.h) into the batch's buffer (inflate stream)
+//   k_bgzf_crc      one wave per block: CRC-32 of the inflated bytes against the block's trailer (coral_crc32.h)
 //   k_bam_find      one wave per 128 KiB segment: first plausible record start (chained check) + hop along block_size
 //   k_bam_verify    one workgroup: follows the chain of segment landings from the batch's KNOWN first record; a segment
 //                   whose guess is not on the chain is re-walked exactly, so record boundaries never rest on a heuristic
@@ -15,9 +16,10 @@
 //   (hipcub scans)  offsets of CIGAR ops (padded to 4), read-name bytes and SA text
 //   k_bam_emit      one wave per record: CIGAR -> padded SoA op array (+ reference / query lengths), SEQ scan for non-ACGT
 //                   codes, read name and SA text -> compact blobs for the host
-//   host            per batch, a few hundred bytes per record: read names -> ids, SA text -> numeric rows; the rare
-//                   records with non-ACGT bases are fetched whole and handled by the CPU pipeline's own routine.
-// Batches (<= 1 GiB inflated) are double-buffered: while batch k is parsed, batch k + 1 is inflated and k + 2 is read.
+//   worker thread   per batch, a few hundred bytes per record: read names -> ids, SA text -> numeric rows; the rare
+//                   records with non-ACGT bases are gathered whole (k_bam_gather) and handled by the CPU pipeline's own routine.
+// Batches (64 MiB first, doubling up to 1 GiB inflated) are double-buffered: while batch k is parsed, batch k + 1 is inflated
+// and k + 2 is read.
 // A record that straddles two batches is carried in front of the next batch's buffer.
 //
 // Multi-GPU: rank r of `world` decodes the BGZF blocks that start in its byte range of the file, with the

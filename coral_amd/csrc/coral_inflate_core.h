@@ -1,10 +1,10 @@
 // coral_inflate_core.h — RFC 1951 (DEFLATE) decoder core of the GPU BGZF path (coral_bamgpu.hip).
 //
 // One 64-lane wave inflates one BGZF block (<= 64 KiB of output, one gzip member).  Symbol decoding is serial by nature and
-// runs as WAVE-UNIFORM code (every lane computes the same values; the table entry read from LDS is made scalar with
-// readfirstlane), the lanes do what is parallel: building the Huffman lookup tables (one table entry per lane and step),
-// holding the next 256 input bytes in a register (the bit buffer is refilled with v_readlane, never from memory), parking up
-// to 64 literals in a register until a full line can be stored, and copying LZ77 matches 64 bytes per step.
+// runs as WAVE-UNIFORM code (every lane computes the same values; what feeds a branch is made scalar with readfirstlane, the
+// rest stays on the vector pipe), the lanes do what is parallel: building the Huffman lookup tables (one table entry per lane
+// and step), holding the next 256 input bytes in a register (the bit buffer is refilled with v_readlane, never from memory),
+// and copying LZ77 matches 64 bytes per step through a ring of recent output in LDS.
 //
 // The core is written against a small backend interface (`Wave`) so that the very same decode logic also compiles for the
 // host, where tests/test_inflate_core.py drives it against zlib on random, text-like, stored and fixed-Huffman streams (the
@@ -67,8 +67,8 @@ CORAL_HD uint32_t dist_entry(uint32_t d, uint32_t nbits) {
     return make_entry(nbits, 0, e, 1 + ((2 + (d & 1)) << e));
 }
 
-// Backend interface (`W`):
-//   int      lanes_begin() / per-lane execution: `for (int lane : W::lanes())` is spelled W_FOR_LANES(w, lane) below
+// Backend interface (`W`; W::vector_loop selects Inflater::codes_vector, which needs a few more operations, listed there):
+//   per-lane execution is spelled W_FOR_LANES(w, lane) below
 //   uint32_t uni(uint32_t)            make a value read from table memory wave-uniform (device: readfirstlane)
 //   uint32_t next_dword()             the next 32 input bits
 //   void     put_literal(uint32_t b)

@@ -13,6 +13,14 @@ def streams():
              bytes(rnd.choice(b"ACGT") for _ in range(65280)), bytes(rnd.getrandbits(8) & 0x33 for _ in range(30000)),
              b"".join(b"%d,%d;" % (rnd.randrange(1000), rnd.randrange(10 ** 6)) for _ in range(5000))[:65280],
              b"".join(struct.pack("<I", (rnd.randrange(1, 40) << 4) | rnd.choice([0, 0, 0, 1, 2])) for _ in range(16000))]
+    # Fibonacci-like symbol frequencies: Huffman code lengths up to the 15-bit limit (the canonical loop behind the 10-bit table)
+    fib, a, b = [], 1, 1
+    for sym in range(24):
+        fib.append(bytes([65 + sym]) * a)
+        a, b = b, a + b
+    skew = bytearray(b"".join(fib))
+    rnd.shuffle(skew)
+    cases.append(bytes(skew[:65000]))
     for n in (1, 2, 3, 5, 63, 64, 65, 100, 1000, 40000):
         cases.append(os.urandom(n))
         cases.append(bytes(rnd.choice(b"ab") for _ in range(n)))
