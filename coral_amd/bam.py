@@ -88,7 +88,7 @@ def _records_from_handle(L, h, cigar, cigar_words: int) -> Records:
                                        ptr(nm), ptr(name_id), ptr(n_cigar), ptr(cigar_off), ptr(host_cigar) if host_cigar is not None else None,
                                        ptr(sa_off), ptr(sa), ptr(sa_nm), ptr(na_rec), ptr(na_pos), C.addressof(names_buf),
                                        C.addressof(ref_buf), ptr(ref_lens)), "coral_bam_decode_fill")
-    names = names_buf.raw[:nbytes].split(b"\0")[:nnames]
+    names = names_buf.raw[:nbytes].decode().split("\0")[:nnames]       # (one decode + one split: no intermediate bytes objects)
     refs = ref_buf.raw[:rbytes].split(b"\0")[:nref]
     t = torch.from_numpy
     if cigar is None:
@@ -98,7 +98,7 @@ def _records_from_handle(L, h, cigar, cigar_words: int) -> Records:
     return Records(n=n, tid=t(tid), pos=t(pos), end=t(end), flag=t(flag), mapq=t(mapq), qlen=t(qlen), has_seq=t(has_seq),
                    nm=t(nm), name_id=t(name_id), n_cigar=t(n_cigar), cigar_off=t(cigar_off),
                    cigar=cigar, sa_off=t(sa_off), sa=t(sa), sa_nm=t(sa_nm), nonacgt_rec=t(na_rec),
-                   nonacgt_pos=t(na_pos), n_names=nnames, name_gid=None, names=[x.decode() for x in names],
+                   nonacgt_pos=t(na_pos), n_names=nnames, name_gid=None, names=names,
                    header_chroms=[x.decode() for x in refs], header_lens=[int(x) for x in ref_lens])
 
 
