@@ -766,6 +766,9 @@ struct GpuDecoder {
         }
         wcv.notify_all();
         if (worker.joinable()) worker.join();
+        // (an error may leave kernels and copies in flight: they work in the caller's workspace, which is about to be released)
+        if (s_copy) (void)hipStreamSynchronize(s_copy);
+        if (s_infl) (void)hipStreamSynchronize(s_infl);
         for (int i = 0; i < N_STAGE; ++i) {
             if (h_stage[i]) (void)hipHostFree(h_stage[i]);
             if (ev_stage[i]) (void)hipEventDestroy(ev_stage[i]);
@@ -1002,11 +1005,12 @@ void worker_main(GpuDecoder *G) {
     }
 }
 
+// Lays the device workspace out (ws == nullptr: only its size is computed, the pointers stay meaningless).
 bool carve(GpuDecoder *G, void *ws, size_t bytes) {
-    uint8_t *p = (uint8_t *)ws;
+    const uintptr_t p = (uintptr_t)ws;
     size_t used = 0;
     auto take = [&](size_t n) -> void * {
-        void *q = p + used;
+        void *q = (void *)(p + used);
         used += up256(n);
         return q;
     };
