@@ -213,3 +213,30 @@ def test_graph_build_from_gpu_decoded_records(tmp_path):
     a = ibg.build_graph_from_records(DeviceRecords(bam.decode_bam_gpu(p), "cuda:0"), seeds, cn, str(tmp_path / "g"))
     b = ibg.build_graph_from_records(DeviceRecords(bam.decode_bam(p), "cuda:0"), seeds, cn, str(tmp_path / "c"))
     assert [graph_text(g) for g in a.lr_graph] == [graph_text(g) for g in b.lr_graph] and len(a.lr_graph) >= 1
+
+
+def test_bam_file_to_graph_matches_oracle(tmp_path):
+    """The whole chain on a BAM FILE of 30 000 config-3 reads: GPU decode -> graph build, against the CPU oracle working on the host
+    pipeline's decode of the same file (order-normalised graph text; the strict comparison at 2 M reads is tools/validate_full_size.py
+    ... bam, profiles/r02_full_size_parity_from_bam.md)."""
+    from coral_amd import infer_breakpoint_graph as ibg
+    from coral_amd.breakpoint_graph import graph_text
+    from coral_amd.records import DeviceRecords
+    from oracle import coral_oracle as O
+    from oracle.hostrecords import HostRecords
+    from tests.product_check import compare_graph_text
+    cfg = synth.scaled_config("cfg3", 30000)
+    rec = synth.generate(cfg, "cuda:0", chunk_pieces=200000).to("cpu")
+    p = str(tmp_path / "x.bam")
+    bam.write_bam_native(rec, p, seed=1)
+    cn, seeds = str(tmp_path / "cn.bed"), str(tmp_path / "seeds.bed")
+    synth.write_cn_bed(cfg, cn)
+    synth.write_seed_bed(cfg, seeds)
+    b = ibg.build_graph_from_records(DeviceRecords(bam.load_bam(p, "cuda:0"), "cuda:0"), seeds, cn, str(tmp_path / "g"))
+    assert bam.LAST_DECODE["where"] == "gpu"
+    ob, ofiles = O.reconstruct_graph(HostRecords(bam.decode_bam(p)), seeds, cn)
+    assert len(b.lr_graph) == len(ob.lr_graph) >= 1 and b.normal_cov == ob.normal_cov
+    for g, og in zip(b.lr_graph, ob.lr_graph):
+        got = sorted(graph_text(g).splitlines())
+        exp = sorted(O.graph_text(og).splitlines())
+        compare_graph_text("\n".join(got), "\n".join(exp))
