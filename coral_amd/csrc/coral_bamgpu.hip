@@ -729,7 +729,7 @@ struct GpuDecoder {
     bool feeder_done = false, stop = false;
     int inflate_launched = 0;                 // batches whose inflate kernel has been enqueued
     int emitted = 0;                          // batches whose parse has been enqueued completely (ev_parsed recorded)
-    std::string feeder_error;
+    std::string feeder_error, launch_error;
     // walk state
     int k = 0;                                // next batch to parse
     bool searching = false, finished = false;
@@ -811,6 +811,8 @@ bool read_range(int fd, uint64_t off, size_t n, uint8_t *dst, int n_threads) {
     for (auto &t : th) t.join();
     return !bad;
 }
+
+bool launch_inflate(GpuDecoder *G, int kb, const BatchInfo &bi);
 
 // The feeder: cuts the byte range into batches (whole BGZF blocks, <= infl_cap inflated and <= comp_cap compressed bytes),
 // reads each into pinned memory, builds its block table and sends both to the device.
@@ -907,16 +909,8 @@ void feeder_main(GpuDecoder *G) {
         }
         ubase += infl;
         bi.last = at >= G->f.size || (own_bytes >= 0 && overhang_left == 0);
-        // the block table and the trailer CRCs go through their own pinned buffer (one per batch slot).  The device copies of the
-        // slot are still read by the checksum kernel of batch kb - 2 until that batch has been parsed.
-        if (kb >= 2) {
-            {
-                std::unique_lock<std::mutex> lk(G->m);
-                G->cv.wait(lk, [&] { return G->stop || G->emitted >= kb - 1; });
-                if (G->stop) return;
-            }
-            if (hipEventSynchronize(G->ev_parsed[slot]) != hipSuccess) return fail("hipEventSynchronize failed in the feeder");
-        }
+        // the block table and the trailer CRCs go through their own pinned buffer (one per batch slot; host and device copies are
+        // free again once the slot's inflate + checksum kernels have run: see the wait at the top of the round)
         memcpy(G->h_desc[slot], desc.data(), desc.size() * sizeof(BlockDesc));
         uint32_t *h_crc = reinterpret_cast<uint32_t *>(G->h_desc[slot] + G->max_blocks);
         memcpy(h_crc, crcs.data(), crcs.size() * 4);
@@ -929,6 +923,14 @@ void feeder_main(GpuDecoder *G) {
             G->staged.push_back(bi);
         }
         G->cv.notify_all();
+        // ... and its inflate is enqueued from here as well, as soon as the batch that used this slot's inflated buffer before
+        // (kb - 2) has been parsed: the GPU never waits for the caller's thread to come round
+        {
+            std::unique_lock<std::mutex> lk(G->m);
+            G->cv.wait(lk, [&] { return G->stop || G->emitted >= kb - 1; });
+            if (G->stop) return;
+        }
+        if (!launch_inflate(G, kb, bi)) return fail(G->launch_error);
         ++kb;
         if (bi.last) break;
     }
@@ -1049,15 +1051,29 @@ bool carve(GpuDecoder *G, void *ws, size_t bytes) {
     return true;
 }
 
+#define HIP_LAUNCH_OK(call, what)                                                           \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            G->launch_error = std::string(what) + ": " + hipGetErrorString(e_);             \
+            return false;                                                                   \
+        }                                                                                   \
+    } while (0)
+
 bool launch_inflate(GpuDecoder *G, int kb, const BatchInfo &bi) {
     const int slot = kb & 1;
-    HIP_OK(hipStreamWaitEvent(G->s_infl, G->ev_h2d[slot], 0), "hipStreamWaitEvent");
-    if (kb >= 2) HIP_OK(hipStreamWaitEvent(G->s_infl, G->ev_parsed[slot], 0), "hipStreamWaitEvent");     // the buffer's previous batch has been parsed
+    HIP_LAUNCH_OK(hipStreamWaitEvent(G->s_infl, G->ev_h2d[slot], 0), "hipStreamWaitEvent");
+    if (kb >= 2) HIP_LAUNCH_OK(hipStreamWaitEvent(G->s_infl, G->ev_parsed[slot], 0), "hipStreamWaitEvent");     // the buffer's previous batch has been parsed
     const int grid = (bi.n_blocks + INFL_WAVES - 1) / INFL_WAVES;
     hipLaunchKernelGGL(k_bgzf_inflate<0>, dim3(grid), dim3(INFL_WAVES * WAVE), 0, G->s_infl, G->d_comp[slot], G->d_desc[slot], bi.n_blocks,
                        G->d_infl[slot] + CARRY_CAP, G->d_status[slot]);
-    HIP_OK(hipGetLastError(), "k_bgzf_inflate");
-    HIP_OK(hipEventRecord(G->ev_infl[slot], G->s_infl), "hipEventRecord");
+    HIP_LAUNCH_OK(hipGetLastError(), "k_bgzf_inflate");
+    // checksums of the inflated blocks (as htslib's bgzf_read_block): a mismatch becomes the block's status.  On the inflate stream,
+    // so that the batch slot's block table and CRCs are free again when ev_infl fires (the feeder reuses them after that).
+    hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)((bi.n_blocks + 3) / 4)), dim3(256), 0, G->s_infl, G->d_infl[slot] + CARRY_CAP, G->d_desc[slot], G->d_crc[slot],
+                       bi.n_blocks, G->d_status[slot]);
+    HIP_LAUNCH_OK(hipGetLastError(), "k_bgzf_crc");
+    HIP_LAUNCH_OK(hipEventRecord(G->ev_infl[slot], G->s_infl), "hipEventRecord");
     {
         std::lock_guard<std::mutex> lk(G->m);
         G->inflate_launched = kb + 1;
@@ -1159,14 +1175,6 @@ extern "C" int coral_bamgpu_start(void *handle, void *workspace, int64_t workspa
     G->t_alloc = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_alloc0).count();
     G->feeder = std::thread(feeder_main, G);
     G->worker = std::thread(worker_main, G);
-    // inflate of batch 0 starts as soon as it is staged
-    BatchInfo b0;
-    if (wait_staged(G, 0, &b0)) {
-        if (!launch_inflate(G, 0, b0)) { set_error(G->error); return CORAL_ERR_HIP; }
-    } else if (!G->error.empty()) {
-        set_error(G->error);
-        return CORAL_ERR_FORMAT;
-    }
     return CORAL_OK;
 }
 
@@ -1192,20 +1200,13 @@ extern "C" int coral_bamgpu_next(void *handle, int64_t out[4], void *stream_) {
     }
     const int kb = G->k, slot = kb & 1;
     uint8_t *buf = G->d_infl[slot];
-    if (G->inflate_launched < kb + 1 && !launch_inflate(G, kb, bi)) return fail(CORAL_ERR_HIP);      // (the feeder was behind)
-    // the inflate of the batch after this one runs while this one is parsed
-    BatchInfo nb;
-    bool have_next = false;
-    {
+    {   // the feeder enqueues the inflate of a batch right after staging it
         std::unique_lock<std::mutex> lk(G->m);
-        have_next = (int)G->staged.size() > kb + 1;
-        if (have_next) nb = G->staged[(size_t)kb + 1];
+        G->cv.wait(lk, [&] { return G->inflate_launched > kb || !G->feeder_error.empty(); });
+        if (G->inflate_launched <= kb) { G->error = G->feeder_error; return fail(CORAL_ERR_HIP); }
     }
     // this batch's inflate must be complete before the parse kernels read its bytes
     if (hipStreamWaitEvent(stream, G->ev_infl[slot], 0) != hipSuccess) { G->error = "hipStreamWaitEvent failed"; return fail(CORAL_ERR_HIP); }
-    // checksums of the inflated blocks (as htslib's bgzf_read_block): a mismatch becomes the block's status
-    hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)((bi.n_blocks + 3) / 4)), dim3(256), 0, stream, buf + CARRY_CAP, G->d_desc[slot], G->d_crc[slot], bi.n_blocks,
-                       G->d_status[slot]);
     const long long data_end = CARRY_CAP + (long long)bi.infl_bytes;
     const long long begin = G->searching ? (long long)CARRY_CAP : std::min(G->known_start, data_end);
     const long long limit = (G->last_rank || !bi.has_limit) ? (1ll << 62) : (long long)CARRY_CAP + bi.limit_rel;
@@ -1219,7 +1220,6 @@ extern "C" int coral_bamgpu_next(void *handle, int64_t out[4], void *stream_) {
         hipLaunchKernelGGL(k_bam_verify, dim3(1), dim3(WAVE), 0, stream, buf, G->searching ? -1ll : G->known_start, begin, data_end, limit, seg0, n_seg,
                            G->d_seg_first, G->d_seg_land, G->d_seg_count, G->d_seg_valid, G->d_seg_base, G->d_result);
     }
-    if (have_next && !launch_inflate(G, kb + 1, nb)) return fail(CORAL_ERR_HIP);
     int32_t status_bad = 0;
     if (n_seg > 0) {
         const auto t_gpu0 = std::chrono::steady_clock::now();
