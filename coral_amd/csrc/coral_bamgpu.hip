@@ -700,6 +700,7 @@ struct GpuDecoder {
     std::string error;
     // capacities
     size_t infl_cap = 0, comp_cap = 0, max_blocks = 0, rec_cap = 0, nseg_cap = 0;
+    uint64_t first_batch = FIRST_BATCH;
     size_t ws_bytes = 0;
     // device workspace (carved from the caller's allocation)
     uint8_t *d_comp[2] = {nullptr, nullptr}, *d_infl[2] = {nullptr, nullptr};
@@ -841,7 +842,7 @@ void feeder_main(GpuDecoder *G) {
         }
         if (kb >= 2 && hipEventSynchronize(G->ev_infl[slot]) != hipSuccess) return fail("hipEventSynchronize failed in the feeder");
         // the first batches are small so that the GPU has something to inflate almost at once; then they double up to the cap
-        const uint64_t infl_cap = std::min<uint64_t>(G->infl_cap, (uint64_t)FIRST_BATCH << std::min(kb, 20));
+        const uint64_t infl_cap = std::min<uint64_t>(G->infl_cap, G->first_batch << std::min(kb, 20));
         const uint64_t comp_cap = std::min<uint64_t>(G->comp_cap, std::max<uint64_t>(infl_cap / 2, 1u << 20));
         BatchInfo bi;
         bi.file_off = at;
@@ -1143,6 +1144,7 @@ extern "C" int coral_bamgpu_open(const char *path, int32_t n_threads, int32_t ra
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, (long long *)nullptr, (long long *)nullptr, (int)std::min<size_t>(G->rec_cap + 1, 0x7fffffff));
     G->scan_tmp_bytes = tmp + 256;
     carve(G.get(), nullptr, 0);
+    if (const char *fb = getenv("CORAL_BAMGPU_FIRST_BATCH")) G->first_batch = std::max<uint64_t>(1u << 20, strtoull(fb, nullptr, 10));      // tuning
     G->known_start = CARRY_CAP + (long long)(rank == 0 ? G->hdr_bytes : 0);
     *workspace_bytes = (int64_t)G->ws_bytes;
     *handle = G.release();
