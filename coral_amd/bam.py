@@ -158,10 +158,10 @@ def decode_bam_gpu(path: str, device="cuda:0", n_threads: Optional[int] = None, 
                            nonacgt_records_fetched=int(gst[2]), batch_bytes=int(gst[3]), host_seconds=float(gsecs[1]), read_seconds=float(gsecs[2]),
                            setup_seconds=float(gsecs[3]), waited_for_file_seconds=float(gsecs[4]), waited_for_gpu_seconds=float(gsecs[5]),
                            workspace_bytes=int(ws_bytes.value))
-        rec = _records_from_handle(L, dh, cigar, total)
-        del ws
-        return rec
+        return _records_from_handle(L, dh, cigar, total)
     finally:
+        # (close drains the decoder's streams — a byte range may have batches of its overhang still being inflated — and only
+        # then the workspace, which those kernels write, is released: `ws` lives until this function returns)
         L.coral_bamgpu_close(h)
 
 
