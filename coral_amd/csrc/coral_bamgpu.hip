@@ -1210,7 +1210,7 @@ extern "C" int coral_bamgpu_next(void *handle, int64_t out[4], void *stream_) {
     // this batch's inflate must be complete before the parse kernels read its bytes
     if (hipStreamWaitEvent(stream, G->ev_infl[slot], 0) != hipSuccess) { G->error = "hipStreamWaitEvent failed"; return fail(CORAL_ERR_HIP); }
     const long long data_end = CARRY_CAP + (long long)bi.infl_bytes;
-    const long long begin = G->searching ? (long long)CARRY_CAP : std::min(G->known_start, data_end);
+    const long long begin = G->searching ? (long long)CARRY_CAP - G->carry_len : std::min(G->known_start, data_end);
     const long long limit = (G->last_rank || !bi.has_limit) ? (1ll << 62) : (long long)CARRY_CAP + bi.limit_rel;
     const int seg0 = (int)(begin / SEG_BYTES);
     const int n_seg = (int)((data_end + SEG_BYTES - 1) / SEG_BYTES) - seg0;
@@ -1243,12 +1243,22 @@ extern "C" int coral_bamgpu_next(void *handle, int64_t out[4], void *stream_) {
         if (status_bad) { G->error = "inflate failed (corrupt BGZF block), code " + std::to_string(status_bad); return fail(CORAL_ERR_FORMAT); }
     }
     if (res[3] == 1) { G->error = "record shorter than its fixed fields"; return fail(CORAL_ERR_FORMAT); }
-    if (res[3] == 2) { G->error = "no record start found in the first batch of the byte range"; return fail(CORAL_ERR_FORMAT); }
+    bool still_searching = false;
+    if (res[3] == 2) {
+        // no confirmed record start in what this byte range has seen so far (the chained check needs three records in a row): keep
+        // the bytes and look again with the next batch behind them, as the host pipeline does; at the end of the range it simply
+        // has no record of its own (it lies inside one record of the previous range)
+        if (data_end - begin > CARRY_CAP) { G->error = "no record start found in 64 MiB at the beginning of the byte range"; return fail(CORAL_ERR_FORMAT); }
+        res[0] = 0;
+        res[1] = bi.last ? data_end : begin;
+        res[2] = 0;
+        still_searching = !bi.last;
+    }
     const long long n_rec = res[0], carry_pos = res[1];
     G->cur_carry_pos = carry_pos < data_end ? carry_pos : data_end;
     G->fixups += res[4];
     if (n_rec > (long long)G->rec_cap) { G->error = "more records in a batch than its workspace holds"; return fail(CORAL_ERR_FORMAT); }
-    G->searching = false;
+    G->searching = still_searching;
     G->cur = bi;
     G->cur_n_rec = n_rec;
     G->cur_ops = G->cur_name_bytes = G->cur_sa_bytes = 0;
@@ -1285,7 +1295,7 @@ extern "C" int coral_bamgpu_next(void *handle, int64_t out[4], void *stream_) {
         G->carry_len = 0;
     } else if (carry_pos < data_end) {
         G->carry_len = data_end - carry_pos;
-        if (G->carry_len > CARRY_CAP) { G->error = "a record larger than 256 MiB straddles two batches"; return fail(CORAL_ERR_FORMAT); }
+        if (G->carry_len > CARRY_CAP) { G->error = "a record larger than 64 MiB straddles two batches"; return fail(CORAL_ERR_FORMAT); }
         G->known_start = CARRY_CAP - G->carry_len;
     } else {
         G->carry_len = 0;

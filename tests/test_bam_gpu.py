@@ -133,6 +133,10 @@ def test_gpu_byte_ranges_partition_the_file(config, n_reads, tmp_path):
         got = _concat(parts)
         for k, v in whole.items():
             assert (list(v) == list(got[k])) if k == "names" else np.array_equal(v, got[k]), (world, k)
+    # batches so small that a range's first batch may not hold three records in a row: the search for the range's first record
+    # then goes on over several batches (as the host pipeline's does over its chunks)
+    for r in range(3):
+        _same_records(bam.decode_bam_gpu(p, rank=r, world=3, batch_bytes=1 << 20), bam.decode_bam(p, n_threads=2, rank=r, world=3))
 
 
 def test_gpu_decode_small_files(tmp_path):
