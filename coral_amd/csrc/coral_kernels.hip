@@ -269,6 +269,13 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v4(
     // bounds of the next group are loaded while the current one is processed: a group change costs no dependent round trip.
     const long long total_q = cigar_off[n_rec] >> 2;
     const int last_rec = (int)n_rec - 1;                         // n_rec < 2^31
+    if (group <= 0) {
+        // a group is sized by WORK, ~11 000 quads (44 000 ops: 24 records of config 3, the measured optimum there; 6 records of
+        // config 5's 100 kb reads, where 24-record groups left waves with one group more than others: 1.67 -> 1.46 ms)
+        const long long avg_q = total_q / n_rec > 0 ? total_q / n_rec : 1;
+        const long long gq = 11000 / avg_q;
+        group = (int)(gq < 1 ? 1 : gq > 24 ? 24 : gq);
+    }
     const int n_groups = (int)((n_rec + group - 1) / group);
     const int dyn_base = 2 * (int)nwaves;                        // first group id the cursor hands out
     int g = (int)wave, g_next = (int)(wave + nwaves);
@@ -512,7 +519,7 @@ static int check_records(const coral_records_t *rec) {
 // workgroups of the scan: as many as are resident at once (register-bound), never more waves than records.
 // CORAL_SCAN_RING (4 / 6 / 8 / 12), CORAL_SCAN_GROUP (1 .. 64) and CORAL_SCAN_WG_PER_CU: tuning overrides (tools/scan_sweep.sh).
 #define SCAN_RING_DEFAULT 6
-static int g_ring = 0, g_wg_per_cu = 0, g_group = 24;
+static int g_ring = 0, g_wg_per_cu = 0, g_group = 0;          // g_group 0: the kernel sizes its groups by CIGAR ops (see there)
 template <int RING>
 static int scan_grid(long long n_rec) {
     int per_cu = 0, dev = 0, cus = 0;
@@ -540,9 +547,12 @@ extern "C" int coral_cigar_scan(const coral_records_t *rec, int32_t min_gap, int
         if (c && atoi(c) >= 1 && atoi(c) <= 64) g_group = atoi(c);
     }
 #define LAUNCH_V4(R)                                                                                                              \
-    hipLaunchKernelGGL(k_cigar_scan_v4<R>, dim3(scan_grid<R>(rec->n_rec)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,              \
-                       (long long)rec->n_rec, rec->pos, rec->flagmq, rec->cigar_off, rec->cigar, (int)min_gap, (int)min_mapq,     \
-                       reinterpret_cast<int4 *>(summary), gaps, gap_count, gap_cap, g_group)
+    do {                                                                                                                          \
+        const int blocks_ = scan_grid<R>(rec->n_rec);                                                                             \
+        hipLaunchKernelGGL(k_cigar_scan_v4<R>, dim3(blocks_), dim3(SCAN_BLOCK), 0, (hipStream_t)stream,                           \
+                           (long long)rec->n_rec, rec->pos, rec->flagmq, rec->cigar_off, rec->cigar, (int)min_gap, (int)min_mapq, \
+                           reinterpret_cast<int4 *>(summary), gaps, gap_count, gap_cap, g_group);                                 \
+    } while (0)
     if (g_ring == 4) LAUNCH_V4(4);
     else if (g_ring == 8) LAUNCH_V4(8);
     else if (g_ring == 12) LAUNCH_V4(12);
