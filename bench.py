@@ -47,14 +47,34 @@ def main():
     ap.add_argument("--mode", default="shard", choices=["shard", "samples"],
                     help="N > 1: 'shard' (default) = ONE sample, records sharded over the GPUs, exchange over RCCL (strong scaling); "
                          "'samples' = one independent sample per GPU, no collective on the data path (weak scaling, cohort use)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="N > 1 without a launcher: the rank processes only print their RANK / LOCAL_RANK / WORLD_SIZE and exit (CPU test)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without torch.distributed.run: this process becomes the launcher.  Nothing has touched the
+        # GPU yet (torch is not even imported), and it never will here: the ranks are fresh child processes.
+        sys.exit(launch_ranks(a.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N`, or under torch.distributed.run "
+                 "with --nproc-per-node equal to --gpus)" % (a.gpus, world))
+    if a.dry_launch:
+        if os.environ.get("CORAL_BENCH_DRY_FAIL_RANK") == os.environ.get("RANK", "0"):      # (test hook: a rank that dies)
+            sys.exit(3)
+        print(json.dumps({"dry_launch": True, "rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+                          "world": int(os.environ.get("WORLD_SIZE", "1")), "master": "%s:%s" % (os.environ.get("MASTER_ADDR"),
+                                                                                                 os.environ.get("MASTER_PORT"))}), flush=True)
+        return
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    if not a.shared_gpu and torch.cuda.device_count() < world:          # (counting devices does not initialise the GPU)
+        sys.exit("bench.py: --gpus %d but only %d GPU(s) are visible (a one-GPU rehearsal of N > 1 is --shared-gpu --backend gloo)"
+                 % (world, torch.cuda.device_count()))
     if a.shared_gpu:
         local = 0
     torch.cuda.set_device(local)
@@ -169,6 +189,64 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     shutil.rmtree(work, ignore_errors=True)
+
+
+def launch_ranks(n: int) -> int:
+    """The launcher side of `python bench.py --gpus N` (no torch.distributed.run around it): start N rank processes of this same
+    script — one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment — relay their output
+    (rank 0's stdout, which carries the ONE JSON line, to stdout; everything else to stderr) and return non-zero if any rank
+    fails.  Children are started with Popen from a process that has made no GPU call; nothing is exec'ed over a process."""
+    import socket
+    import subprocess
+    import threading
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+
+    def relay():
+        for line in procs[0].stdout:
+            sys.stdout.write(line.decode(errors="replace"))
+            sys.stdout.flush()
+
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    rc = 0
+    try:
+        # a rank that dies leaves the others waiting in a collective: poll, and end the rest as soon as one has failed
+        alive = set(range(n))
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is not None:
+                    alive.discard(r)
+                    if code != 0:
+                        sys.stderr.write("bench.py launcher: rank %d exited with code %d\n" % (r, code))
+                        rc = rc or (code if code > 0 else 1)
+            if rc and alive:
+                time.sleep(5.0)
+                for r in alive:
+                    procs[r].terminate()
+                for r in alive:
+                    try:
+                        procs[r].wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        procs[r].kill()
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    t.join(timeout=10)
+    return rc
 
 
 def measure_h2d(dr):

@@ -92,9 +92,11 @@ def lib():
     L.coral_cluster_first_fit.restype = C.c_int
     L.coral_bam_decode_open.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]
     L.coral_bam_decode_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
-    L.coral_bam_decode_fill.argtypes = [C.c_void_p] + [P] * 20
+    L.coral_bam_decode_fill.argtypes = [C.c_void_p] + [P] * 21
     L.coral_bam_decode_close.argtypes = [C.c_void_p]
     L.coral_bam_last_error.restype = C.c_char_p
+    L.coral_names_unify.argtypes = [C.c_int32, P, P, P, P, P, P, C.POINTER(C.c_int64), C.c_int32]
+    L.coral_names_unify.restype = C.c_int
     L.coral_bam_decode_range.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     L.coral_bam_decode_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.coral_bam_write.argtypes = [C.c_char_p, C.c_int64] + [P] * 9 + [P, P, P, P, P, C.c_int64, P, P, P, C.c_int32, P, P, C.c_uint32,

@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .names import NameTable
 from .synth import Records, hash_u32, S_SEQ, sa_entry_string
 
 
@@ -80,15 +81,16 @@ def _records_from_handle(L, h, cigar, cigar_words: int) -> Records:
     sa_nm = i32(nsa)
     na_rec = np.empty(nna, dtype=np.int64)
     na_pos = i32(nna)
-    names_buf = C.create_string_buffer(max(nbytes, 1))
+    names_blob = np.empty(max(nbytes, 1), dtype=np.uint8)
+    name_off = np.zeros(nnames + 1, dtype=np.int64)
     ref_buf = C.create_string_buffer(max(rbytes, 1))
     ref_lens = i32(nref)
     ptr = lambda a: a.ctypes.data
     _lib.check(L.coral_bam_decode_fill(h, ptr(tid), ptr(pos), ptr(end), ptr(flag), ptr(mapq), ptr(qlen), ptr(has_seq),
                                        ptr(nm), ptr(name_id), ptr(n_cigar), ptr(cigar_off), ptr(host_cigar) if host_cigar is not None else None,
-                                       ptr(sa_off), ptr(sa), ptr(sa_nm), ptr(na_rec), ptr(na_pos), C.addressof(names_buf),
-                                       C.addressof(ref_buf), ptr(ref_lens)), "coral_bam_decode_fill")
-    names = names_buf.raw[:nbytes].decode().split("\0")[:nnames]       # (one decode + one split: no intermediate bytes objects)
+                                       ptr(sa_off), ptr(sa), ptr(sa_nm), ptr(na_rec), ptr(na_pos), ptr(names_blob),
+                                       ptr(name_off), C.addressof(ref_buf), ptr(ref_lens)), "coral_bam_decode_fill")
+    names = NameTable(names_blob[:nbytes], name_off)                  # the names stay bytes: a str is made when one is asked for
     refs = ref_buf.raw[:rbytes].split(b"\0")[:nref]
     t = torch.from_numpy
     if cigar is None:

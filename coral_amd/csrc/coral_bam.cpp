@@ -140,8 +140,7 @@ bool decode_file(const char *path, int n_threads, int rank, int world, Decoded &
     };
     auto wait = [&](Flag &fl) { while (!fl.get()) if (!pool.help_one()) std::this_thread::yield(); };
 
-    std::unordered_map<std::string, int32_t> name_id;
-    name_id.reserve(1 << 20);
+    D.names.grow(1 << 21);
     auto merge = [&](Chunk &c) -> bool {
         Partial &pt = c.part;
         if (!pt.error.empty()) { D.error = pt.error; return false; }
@@ -157,13 +156,7 @@ bool decode_file(const char *path, int n_threads, int rank, int world, Decoded &
         app(D.na_pos, pt.na_pos);
         for (const char *s = pt.names.data(), *e = s + pt.names.size(); s < e;) {
             const size_t len = strlen(s);
-            std::string nm(s, len);
-            auto it = name_id.find(nm);
-            if (it == name_id.end()) {
-                it = name_id.emplace(nm, (int32_t)D.names.size()).first;
-                D.names.push_back(nm);
-            }
-            D.name_id.push_back(it->second);
+            D.name_id.push_back(D.names.intern(s, len));
             s += len + 1;
         }
         c.part = Partial();
@@ -461,8 +454,7 @@ extern "C" int coral_bam_decode_open(const char *path, int32_t n_threads, void *
 extern "C" int coral_bam_decode_sizes(void *handle, int64_t sizes[8]) {
     if (!handle || !sizes) return CORAL_ERR_ARG;
     Decoded *D = (Decoded *)handle;
-    int64_t nb = 0, rb = 0;
-    for (auto &s : D->names) nb += (int64_t)s.size() + 1;
+    int64_t nb = (int64_t)D->names.blob.size(), rb = 0;
     for (auto &s : D->ref_names) rb += (int64_t)s.size() + 1;
     sizes[0] = (int64_t)D->tid.size();
     sizes[1] = (int64_t)D->cigar.size();
@@ -488,7 +480,8 @@ extern "C" int coral_bam_decode_stats(void *handle, int64_t stats[3], double *se
 extern "C" int coral_bam_decode_fill(void *handle, int32_t *tid, int32_t *pos, int32_t *end, int32_t *flag, int32_t *mapq,
                                      int32_t *qlen, int32_t *has_seq, int32_t *nm, int32_t *name_id, int32_t *n_cigar,
                                      int64_t *cigar_off, uint32_t *cigar, int64_t *sa_off, int32_t *sa, int32_t *sa_nm,
-                                     int64_t *na_rec, int32_t *na_pos, char *names, char *ref_names, int32_t *ref_lens) {
+                                     int64_t *na_rec, int32_t *na_pos, char *names, int64_t *name_off, char *ref_names,
+                                     int32_t *ref_lens) {
     if (!handle) return CORAL_ERR_ARG;
     Decoded *D = (Decoded *)handle;
     auto cp = [](auto *dst, const auto &v) { if (!v.empty()) memcpy(dst, v.data(), v.size() * sizeof(v[0])); };
@@ -496,9 +489,8 @@ extern "C" int coral_bam_decode_fill(void *handle, int32_t *tid, int32_t *pos, i
     cp(has_seq, D->has_seq); cp(nm, D->nm); cp(name_id, D->name_id); cp(n_cigar, D->n_cigar);
     cp(cigar_off, D->cigar_off); cp(cigar, D->cigar); cp(sa_off, D->sa_off); cp(sa, D->sa); cp(sa_nm, D->sa_nm);
     cp(na_rec, D->na_rec); cp(na_pos, D->na_pos); cp(ref_lens, D->ref_lens);
-    char *w = names;
-    for (auto &s : D->names) { memcpy(w, s.c_str(), s.size() + 1); w += s.size() + 1; }
-    w = ref_names;
+    cp(names, D->names.blob); cp(name_off, D->names.off);
+    char *w = ref_names;
     for (auto &s : D->ref_names) { memcpy(w, s.c_str(), s.size() + 1); w += s.size() + 1; }
     return CORAL_OK;
 }

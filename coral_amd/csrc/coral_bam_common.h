@@ -25,6 +25,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include "coral_names.h"
+
 namespace coral_bam {
 
 
@@ -36,7 +38,7 @@ struct Decoded {
     std::vector<int32_t> sa_nm;
     std::vector<int64_t> na_rec;
     std::vector<int32_t> na_pos;
-    std::vector<std::string> names;
+    coral_names::NameIndex names;           // read names: blob + offsets, ids in first-seen order (coral_names.h)
     std::vector<std::string> ref_names;
     std::vector<int32_t> ref_lens;
     std::string error;

@@ -740,7 +740,6 @@ struct GpuDecoder {
     BatchInfo cur;
     long long cur_n_rec = 0, cur_ops = 0, cur_name_bytes = 0, cur_sa_bytes = 0;
     bool have_cur = false;
-    std::unordered_map<std::string, int32_t> name_id;
     // host-side worker
     std::thread worker;
     std::mutex wm;
@@ -963,13 +962,8 @@ void worker_main(GpuDecoder *G) {
             D.cigar_off.push_back(D.cigar_off.back() + J.pad[(size_t)i]);
             const char *s = (const char *)J.names.data() + J.name_off[(size_t)i];
             const size_t len = (size_t)(J.name_off[(size_t)i + 1] - J.name_off[(size_t)i]);
-            std::string nmstr(s, len ? strnlen(s, len - 1) : 0);          // as the CPU pipeline: the bytes in front of the last one, cut at a NUL
-            auto it = G->name_id.find(nmstr);
-            if (it == G->name_id.end()) {
-                it = G->name_id.emplace(nmstr, (int32_t)D.names.size()).first;
-                D.names.push_back(nmstr);
-            }
-            D.name_id.push_back(it->second);
+            // as the CPU pipeline: the bytes in front of the last one, cut at a NUL
+            D.name_id.push_back(D.names.intern(s, len ? strnlen(s, len - 1) : 0));
             int32_t cnt = 0;
             if (J.sa_off[(size_t)i + 1] > J.sa_off[(size_t)i]) {
                 const char *q = (const char *)J.sa_text.data() + J.sa_off[(size_t)i];

@@ -7,11 +7,13 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <exception>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
 #include "../../include/coral_hip.h"
+#include "coral_names.h"
 #include "pyset_emu.h"
 
 namespace {
@@ -309,6 +311,27 @@ extern "C" int coral_concordant_counts(int32_t n_edges, const int64_t *pt_off, c
             }
         }
         count[q] = c;
+    }
+    return CORAL_OK;
+}
+
+
+// Read-name tables of consecutive byte ranges of one file -> one table numbered by first appearance over the file
+// (coral_names.h: unify).  What rank 0 does with the gathered per-rank decodes; replaces a Python dict over 2 M str.
+extern "C" int coral_names_unify(int32_t n_pieces, const int64_t *n_names, const uint8_t *const *blob, const int64_t *const *off,
+                                 int32_t *const *lut, uint8_t *out_blob, int64_t *out_off, int64_t *n_global, int32_t n_threads) {
+    if (n_pieces < 0 || !n_global || !out_off || (n_pieces > 0 && (!n_names || !blob || !off || !lut))) return CORAL_ERR_ARG;
+    int64_t total = 0;
+    for (int32_t p = 0; p < n_pieces; ++p) {
+        if (n_names[p] < 0 || (n_names[p] > 0 && (!blob[p] || !off[p] || !lut[p]))) return CORAL_ERR_ARG;
+        total += n_names[p];
+    }
+    if (total > 0x7FFFFFFF) return CORAL_ERR_ARG;             // name ids are int32 throughout
+    if (total > 0 && !out_blob) return CORAL_ERR_ARG;
+    try {
+        *n_global = coral_names::unify(n_pieces, n_names, blob, off, lut, out_blob, out_off, n_threads);
+    } catch (const std::exception &) {
+        return CORAL_ERR_ARG;
     }
     return CORAL_OK;
 }

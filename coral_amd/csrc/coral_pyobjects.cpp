@@ -125,10 +125,155 @@ PyObject *count_distinct3(PyObject *, PyObject *args) {
     return PyLong_FromSsize_t(distinct);
 }
 
+// ---- read names kept as ONE byte blob + offsets (coral_amd/names.py: NameTable) ----------------------------------------
+struct BlobView {
+    Py_buffer blob, off;
+    bool ok_blob = false, ok_off = false;
+    const char *b = nullptr;
+    const int64_t *o = nullptr;
+    Py_ssize_t n = 0;          // number of names
+    bool get(PyObject *blob_o, PyObject *off_o) {
+        if (PyObject_GetBuffer(blob_o, &blob, PyBUF_C_CONTIGUOUS) != 0) return false;
+        ok_blob = true;
+        if (PyObject_GetBuffer(off_o, &off, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) != 0) return false;
+        ok_off = true;
+        if (off.itemsize != 8 || off.ndim != 1 || off.shape[0] < 1) {
+            PyErr_SetString(PyExc_TypeError, "off must be a contiguous one-dimensional int64 array of n + 1 offsets");
+            return false;
+        }
+        b = static_cast<const char *>(blob.buf);
+        o = static_cast<const int64_t *>(off.buf);
+        n = off.shape[0] - 1;
+        if (o[0] < 0 || o[n] > blob.len) {
+            PyErr_SetString(PyExc_ValueError, "name offsets exceed the blob");
+            return false;
+        }
+        return true;
+    }
+    // a new str for name id (UTF-8, which ASCII read names are)
+    PyObject *str(int64_t id) const {
+        if (id < 0 || id >= n || o[id + 1] < o[id]) {
+            PyErr_SetString(PyExc_IndexError, "name id out of range");
+            return nullptr;
+        }
+        return PyUnicode_DecodeUTF8(b + o[id], (Py_ssize_t)(o[id + 1] - o[id]), "strict");
+    }
+    ~BlobView() {
+        if (ok_blob) PyBuffer_Release(&blob);
+        if (ok_off) PyBuffer_Release(&off);
+    }
+};
+
+// blob_names(blob, off, ids | None) -> [str(name ids[k]) ...]   (None: every name, in id order)
+PyObject *blob_names(PyObject *, PyObject *args) {
+    PyObject *blob_o, *off_o, *ids_o;
+    if (!PyArg_ParseTuple(args, "OOO", &blob_o, &off_o, &ids_o)) return nullptr;
+    BlobView B;
+    if (!B.get(blob_o, off_o)) return nullptr;
+    I64View ids;
+    const bool all = ids_o == Py_None;
+    if (!all && !ids.get(ids_o, "ids")) return nullptr;
+    const Py_ssize_t n = all ? B.n : ids.n;
+    PyObject *out = PyList_New(n);
+    if (!out) return nullptr;
+    for (Py_ssize_t k = 0; k < n; ++k) {
+        PyObject *s = B.str(all ? (int64_t)k : ids.p[k]);
+        if (!s) {
+            Py_DECREF(out);
+            return nullptr;
+        }
+        PyList_SET_ITEM(out, k, s);
+    }
+    return out;
+}
+
+// blob_tuples(blob, off, ids, i, j) -> [(name, int(i[k]), int(j[k])) ...]
+PyObject *blob_tuples(PyObject *, PyObject *args) {
+    PyObject *blob_o, *off_o, *ids_o, *i_o, *j_o;
+    if (!PyArg_ParseTuple(args, "OOOOO", &blob_o, &off_o, &ids_o, &i_o, &j_o)) return nullptr;
+    BlobView B;
+    if (!B.get(blob_o, off_o)) return nullptr;
+    I64View ids, vi, vj;
+    if (!ids.get(ids_o, "ids") || !vi.get(i_o, "i") || !vj.get(j_o, "j")) return nullptr;
+    if (vi.n != ids.n || vj.n != ids.n) {
+        PyErr_SetString(PyExc_ValueError, "ids, i and j must have the same length");
+        return nullptr;
+    }
+    PyObject *out = PyList_New(ids.n);
+    if (!out) return nullptr;
+    for (Py_ssize_t k = 0; k < ids.n; ++k) {
+        PyObject *s = B.str(ids.p[k]);
+        PyObject *a = s ? PyLong_FromLongLong(vi.p[k]) : nullptr;
+        PyObject *b = a ? PyLong_FromLongLong(vj.p[k]) : nullptr;
+        PyObject *t = b ? PyTuple_New(3) : nullptr;
+        if (!t) {
+            Py_XDECREF(s);
+            Py_XDECREF(a);
+            Py_XDECREF(b);
+            Py_DECREF(out);
+            return nullptr;
+        }
+        PyTuple_SET_ITEM(t, 0, s);
+        PyTuple_SET_ITEM(t, 1, a);
+        PyTuple_SET_ITEM(t, 2, b);
+        PyList_SET_ITEM(out, k, t);
+    }
+    return out;
+}
+
+// blob_hashes(blob, off, ids, out) : out[k] = hash(str(name ids[k])) — THIS interpreter's str hash (its algorithm and its
+// per-process key), which is what orders the reference's sets of read names (ibg:379-384, :412-418).  An ASCII str hashes
+// its bytes (_Py_HashBytes over the one-byte-per-character buffer), so neither the str nor a Python-level loop is needed;
+// a name with a byte >= 0x80 goes through a real str.
+PyObject *blob_hashes(PyObject *, PyObject *args) {
+    PyObject *blob_o, *off_o, *ids_o, *out_o;
+    if (!PyArg_ParseTuple(args, "OOOO", &blob_o, &off_o, &ids_o, &out_o)) return nullptr;
+    BlobView B;
+    if (!B.get(blob_o, off_o)) return nullptr;
+    I64View ids;
+    if (!ids.get(ids_o, "ids")) return nullptr;
+    Py_buffer ob;
+    if (PyObject_GetBuffer(out_o, &ob, PyBUF_C_CONTIGUOUS | PyBUF_WRITABLE | PyBUF_FORMAT) != 0) return nullptr;
+    if (ob.itemsize != 8 || ob.ndim != 1 || ob.shape[0] != ids.n) {
+        PyBuffer_Release(&ob);
+        PyErr_SetString(PyExc_TypeError, "out must be a writable int64 array as long as ids");
+        return nullptr;
+    }
+    int64_t *out = static_cast<int64_t *>(ob.buf);
+    for (Py_ssize_t k = 0; k < ids.n; ++k) {
+        const int64_t id = ids.p[k];
+        if (id < 0 || id >= B.n) {
+            PyBuffer_Release(&ob);
+            PyErr_SetString(PyExc_IndexError, "name id out of range");
+            return nullptr;
+        }
+        const char *s = B.b + B.o[id];
+        const Py_ssize_t len = (Py_ssize_t)(B.o[id + 1] - B.o[id]);
+        bool ascii = true;
+        for (Py_ssize_t q = 0; q < len; ++q) ascii &= ((unsigned char)s[q] < 0x80);
+        if (ascii) {
+            out[k] = (int64_t)_Py_HashBytes(s, len);
+        } else {
+            PyObject *u = B.str(id);
+            if (!u) {
+                PyBuffer_Release(&ob);
+                return nullptr;
+            }
+            out[k] = (int64_t)PyObject_Hash(u);
+            Py_DECREF(u);
+        }
+    }
+    PyBuffer_Release(&ob);
+    Py_RETURN_NONE;
+}
+
 PyMethodDef methods[] = {
     {"names_of", names_of, METH_VARARGS, "names_of(names, ids) -> [names[k] for k in ids]  (ids: contiguous int64 array)"},
     {"read_tuples", read_tuples, METH_VARARGS, "read_tuples(names, ids, i, j) -> [(names[ids[k]], i[k], j[k]), ...]"},
     {"count_distinct3", count_distinct3, METH_VARARGS, "count_distinct3(a, b, c) -> len(set(zip(a, b, c)))  (contiguous int64 arrays)"},
+    {"blob_names", blob_names, METH_VARARGS, "blob_names(blob, off, ids | None) -> list of str"},
+    {"blob_tuples", blob_tuples, METH_VARARGS, "blob_tuples(blob, off, ids, i, j) -> [(name, i[k], j[k]), ...]"},
+    {"blob_hashes", blob_hashes, METH_VARARGS, "blob_hashes(blob, off, ids, out): out[k] = hash(name ids[k]) of this interpreter"},
     {nullptr, nullptr, 0, nullptr}};
 
 PyModuleDef module = {PyModuleDef_HEAD_INIT, "_pyobjects", "Python containers of the graph build, built with the C API.", -1, methods,

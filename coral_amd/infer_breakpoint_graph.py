@@ -238,10 +238,10 @@ class _RecordsFile:
         else:
             tid = dr.header_chroms.index(contig)
             idx = dr.region(tid, 0 if start is None else start, (1 << 40) if stop is None else stop)
-        names = dr.names
-        for i in idx:
+        names = dr.names.take(dr.h_name_id[idx])
+        for k, i in enumerate(idx):
             r = self._Rec()
-            r.query_name = names[dr.h_name_id[i]]
+            r.query_name = names[k]
             r.mapq = r.mapping_quality = int(dr.h_mapq[i])
             r.reference_name = dr.header_chroms[dr.h_tid[i]]
             r.reference_start = int(dr.h_pos[i])
@@ -597,8 +597,8 @@ class bam_to_breakpoint_nanopore():
 
     # -- candidate clusters -> breakpoints ---------------------------------------------------------
     def _names_of(self, ids) -> list:
-        """Read-name strings of an array of name ids (coral_amd._pyobjects: one C loop, no per-item interpreter work)."""
-        return _pyobjects.names_of(self.rec.names, np.ascontiguousarray(ids, dtype=np.int64))
+        """Read-name strings of an array of name ids (coral_amd.names.NameTable: one C loop, no per-item interpreter work)."""
+        return self.rec.names.take(ids)
 
     def _support(self, c: Candidates, idx) -> ReadSupportSet:
         """The ``set((name, i, j))`` of the candidates ``idx`` (bu:81 / ibg:772) — as arrays until somebody iterates it."""
@@ -629,21 +629,12 @@ class bam_to_breakpoint_nanopore():
 
     # -- BFS helpers ---------------------------------------------------------------------------------
     def _read_hashes(self) -> np.ndarray:
-        """hash(read name) of every chimeric read (index = position in the chimeric table), cached per name id."""
+        """hash(read name) of every chimeric read (index = position in the chimeric table): the interpreter's own str hash,
+        computed from the name bytes (coral_amd.names.NameTable.hashes) — the work behind the reference's set-of-str
+        construction at ibg:379-384, :412-418, without the 164 k str objects."""
         T = self._chim
         if getattr(T, "_hashes", None) is None:
-            dr = self.rec
-            cache = getattr(dr, "_name_hash_cache", None)
-            if cache is None:
-                cache = dr._name_hash_cache = (np.zeros(dr.n_names, dtype=np.int64), np.zeros(dr.n_names, dtype=bool))
-            hv, known = cache
-            ids = T.name_id
-            miss = ids[~known[ids]]
-            if len(miss):
-                names = dr.names
-                hv[miss] = np.fromiter((hash(names[i]) for i in miss.tolist()), dtype=np.int64, count=len(miss))
-                known[miss] = True
-            T._hashes = np.ascontiguousarray(hv[ids])
+            T._hashes = self.rec.names.hashes(T.name_id)
         return T._hashes
 
     def _search(self) -> PairSearch:
@@ -1273,9 +1264,7 @@ class bam_to_breakpoint_nanopore():
             logging.debug(_t() + "There are %d distinct subpaths in total in amplicon %d." % (len(store[0]), amplicon_idx + 1))
 
     def _name_ids(self):
-        if getattr(self, "_name_to_id", None) is None:
-            self._name_to_id = {nm: k for k, nm in enumerate(self.rec.names)}
-        return self._name_to_id
+        return self.rec.names.index_map()
 
     @staticmethod
     def _chain_blocks(entries):
@@ -1407,7 +1396,7 @@ class _LazyReadLength(dict):
         if not self._done:
             self._done = True
             names, rl = self._names, self._rl
-            dict.update(self, {names[i]: int(rl[i]) for i in self._has})
+            dict.update(self, zip(names.take(self._has), rl[self._has].tolist()))
 
     def __len__(self):
         return len(self._has)

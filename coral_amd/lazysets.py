@@ -142,7 +142,7 @@ class ReadSupportSet(_LazySet):
                          np.ascontiguousarray(j, dtype=np.int64))]
 
     def _tuples(self, chunk):
-        return _pyobjects.read_tuples(self._names, *chunk)
+        return self._names.tuples(*chunk)
 
     def _build(self):
         s = set(self._tuples(self._chunks[0]))
@@ -189,7 +189,7 @@ class ReadNameSet(_LazySet):
         return np.ascontiguousarray(self._rec_name[recs], dtype=np.int64)
 
     def _build(self):
-        return set(_pyobjects.names_of(self._names, self._ids(self._left))) | set(_pyobjects.names_of(self._names, self._ids(self._right)))
+        return set(self._names.take(self._ids(self._left))) | set(self._names.take(self._ids(self._right)))
 
     def _drop_arrays(self):
         self._left = self._right = self._rec_name = None

@@ -10,53 +10,100 @@ import numpy as np
 import torch
 
 from . import _lib
+from .names import NameTable
 
 
 class HostMirrors:
     """Per-record fields of the WHOLE file the host logic works on (32 bytes per record, no CIGARs) + tokenised SA rows,
-    non-ACGT positions and read names.  Built from one Records object (single process) or from the gathered per-rank
-    pieces (``from_pieces``: every rank decoded its own byte range of the BAM; read-name ids are unified here)."""
+    non-ACGT positions and read names (``coral_amd.names.NameTable``: one byte blob + offsets, never 2 M ``str``).  Built from
+    one Records object (single process) or from the gathered per-rank pieces (``from_pieces``: every rank decoded its own
+    byte range of the BAM; read-name ids are unified here, natively)."""
 
-    FIELDS = ("tid", "pos", "end", "flag", "mapq", "qlen", "has_seq", "nm", "name_id", "n_cigar", "sa_count", "sa", "sa_nm",
-              "nonacgt_rec", "nonacgt_pos")
+    # what a rank contributes to the gather, in transport order: fixed-width columns, then ONE name blob + its offsets
+    PIECE_SPEC = (("tid", np.int32), ("pos", np.int32), ("end", np.int32), ("flag", np.int32), ("mapq", np.int32), ("qlen", np.int32),
+                  ("has_seq", np.uint8), ("nm", np.int32), ("name_id", np.int32), ("n_cigar", np.int32), ("sa_count", np.int64),
+                  ("sa", np.int32), ("sa_nm", np.int32), ("nonacgt_rec", np.int64), ("nonacgt_pos", np.int32),
+                  ("name_blob", np.uint8), ("name_off", np.int64))
 
     def __init__(self, rec=None):
         if rec is not None:
-            self._from_arrays(HostMirrors.piece_of(rec), names=rec.names, lazy_names=rec)
+            d = HostMirrors.piece_of(rec, with_names=False)
+            self._from_arrays(d, names=rec.names if isinstance(rec.names, NameTable) else None, lazy_names=rec)
 
     @staticmethod
-    def piece_of(rec) -> dict:
+    def piece_of(rec, with_names=True) -> dict:
         """The host-side fields of one Records object as numpy arrays (what a rank contributes to the gather)."""
         h = lambda t: t.detach().cpu().numpy()
         sa_off = h(rec.sa_off).astype(np.int64)
-        return dict(tid=h(rec.tid).astype(np.int32), pos=h(rec.pos).astype(np.int32), end=h(rec.end).astype(np.int32),
-                    flag=h(rec.flag).astype(np.int32), mapq=h(rec.mapq).astype(np.int32), qlen=h(rec.qlen).astype(np.int32),
-                    has_seq=h(rec.has_seq).astype(bool), nm=h(rec.nm).astype(np.int32), name_id=h(rec.name_id).astype(np.int32),
-                    n_cigar=h(rec.n_cigar).astype(np.int32), sa_count=np.diff(sa_off).astype(np.int64),
-                    sa=h(rec.sa).astype(np.int32).reshape(-1, 8), sa_nm=h(rec.sa_nm).astype(np.int32),
-                    nonacgt_rec=h(rec.nonacgt_rec).astype(np.int64), nonacgt_pos=h(rec.nonacgt_pos).astype(np.int32),
-                    n_names=int(rec.n_names))
+        d = dict(tid=h(rec.tid).astype(np.int32), pos=h(rec.pos).astype(np.int32), end=h(rec.end).astype(np.int32),
+                 flag=h(rec.flag).astype(np.int32), mapq=h(rec.mapq).astype(np.int32), qlen=h(rec.qlen).astype(np.int32),
+                 has_seq=h(rec.has_seq).astype(np.uint8), nm=h(rec.nm).astype(np.int32), name_id=h(rec.name_id).astype(np.int32),
+                 n_cigar=h(rec.n_cigar).astype(np.int32), sa_count=np.diff(sa_off).astype(np.int64),
+                 sa=h(rec.sa).astype(np.int32).reshape(-1, 8), sa_nm=h(rec.sa_nm).astype(np.int32),
+                 nonacgt_rec=h(rec.nonacgt_rec).astype(np.int64), nonacgt_pos=h(rec.nonacgt_pos).astype(np.int32),
+                 n_names=int(rec.n_names))
+        if with_names:
+            t = rec.name_table()
+            d["name_blob"], d["name_off"] = t.blob[int(t.off[0]):int(t.off[-1])], t.off - t.off[0]
+        return d
 
     @classmethod
-    def from_pieces(cls, pieces: List[dict], names_per_piece: List[List[str]]) -> "HostMirrors":
-        """Pieces of consecutive record ranges (rank order = file order), each with range-local name ids: one mirror of
-        the whole file.  Global name ids are given in order of first appearance over the file, exactly what a
-        single-process decode gives."""
-        # (C-level loops only: dict.fromkeys keeps the order of first appearance; at 2 M reads a Python loop here costs a second)
-        import itertools
-        names: List[str] = list(dict.fromkeys(itertools.chain.from_iterable(names_per_piece)))
-        index = dict(zip(names, range(len(names))))
-        remapped = []
-        for piece, local_names in zip(pieces, names_per_piece):
-            lut = np.fromiter(map(index.__getitem__, local_names), dtype=np.int32, count=len(local_names)) if local_names else \
-                np.zeros(1, dtype=np.int32)
-            remapped.append(lut[piece["name_id"]] if len(piece["name_id"]) else piece["name_id"])
+    def pack(cls, piece: dict) -> np.ndarray:
+        """One contiguous uint8 buffer: int64 element counts (one per PIECE_SPEC entry), then the raw columns, each starting at
+        a multiple of 8 bytes.  No pickling, no text: the receiver maps the columns in place (``unpack``)."""
+        cols = [np.ascontiguousarray(piece[k], dtype=dt).reshape(-1) for k, dt in cls.PIECE_SPEC]
+        head = np.array([len(c) for c in cols], dtype=np.int64)
+        sizes = [(c.nbytes + 7) & ~7 for c in cols]
+        buf = np.zeros(head.nbytes + sum(sizes), dtype=np.uint8)
+        buf[:head.nbytes] = head.view(np.uint8)
+        at = head.nbytes
+        for c, sz in zip(cols, sizes):
+            buf[at:at + c.nbytes] = c.view(np.uint8)
+            at += sz
+        return buf
+
+    @classmethod
+    def unpack(cls, buf: np.ndarray) -> dict:
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        nh = 8 * len(cls.PIECE_SPEC)
+        head = buf[:nh].view(np.int64)
+        d, at = {}, nh
+        for (k, dt), n in zip(cls.PIECE_SPEC, head.tolist()):
+            nb = n * np.dtype(dt).itemsize
+            d[k] = buf[at:at + nb].view(dt)
+            at += (nb + 7) & ~7
+        d["sa"] = d["sa"].reshape(-1, 8)
+        d["n_names"] = len(d["name_off"]) - 1
+        return d
+
+    @classmethod
+    def from_pieces(cls, pieces: List[dict], n_threads: int = 8) -> "HostMirrors":
+        """Pieces of consecutive record ranges (rank order = file order), each with range-local name ids and its own name
+        table (``name_blob`` / ``name_off``): one mirror of the whole file.  Global name ids are given in order of first
+        appearance over the file, exactly what a single-process decode gives (coral_names_unify: a native hash join over
+        the name bytes — no ``str``, no dict)."""
+        import ctypes as C
+        L = _lib.lib()
+        P = len(pieces)
+        n_names = np.array([len(p["name_off"]) - 1 for p in pieces], dtype=np.int64)
+        blobs = [np.ascontiguousarray(p["name_blob"], dtype=np.uint8) for p in pieces]
+        offs = [np.ascontiguousarray(p["name_off"], dtype=np.int64) for p in pieces]
+        luts = [np.zeros(max(int(n), 1), dtype=np.int32) for n in n_names]
+        out_blob = np.empty(max(sum(len(b) for b in blobs), 1), dtype=np.uint8)
+        out_off = np.zeros(int(n_names.sum()) + 1, dtype=np.int64)
+        arr = lambda xs: (C.c_void_p * max(P, 1))(*[x.ctypes.data for x in xs])
+        n_global = C.c_int64(0)
+        _lib.check(L.coral_names_unify(P, n_names.ctypes.data, arr(blobs), arr(offs), arr(luts), out_blob.ctypes.data,
+                                       out_off.ctypes.data, C.byref(n_global), n_threads), "coral_names_unify")
+        ng = int(n_global.value)
+        names = NameTable(out_blob[:int(out_off[ng])], out_off[:ng + 1])
         cat = lambda k: np.concatenate([p[k] for p in pieces])
         base = np.cumsum([0] + [len(p["tid"]) for p in pieces])
-        d = {k: cat(k) for k in cls.FIELDS if k not in ("name_id", "nonacgt_rec")}
-        d["name_id"] = np.concatenate(remapped).astype(np.int32)
+        d = {k: cat(k) for k, _ in cls.PIECE_SPEC if k not in ("name_id", "nonacgt_rec", "name_blob", "name_off")}
+        d["name_id"] = np.concatenate([lut[p["name_id"]] if len(p["name_id"]) else np.zeros(0, dtype=np.int32)
+                                       for p, lut in zip(pieces, luts)]).astype(np.int32, copy=False)
         d["nonacgt_rec"] = np.concatenate([p["nonacgt_rec"] + base[i] for i, p in enumerate(pieces)])
-        d["n_names"] = len(names)
+        d["n_names"] = ng
         self = cls()
         self._from_arrays(d, names=names, lazy_names=None)
         return self
@@ -64,7 +111,7 @@ class HostMirrors:
     def _from_arrays(self, d: dict, names, lazy_names):
         self.h_tid, self.h_pos, self.h_end = d["tid"], d["pos"], d["end"]
         self.h_flag, self.h_mapq = d["flag"], d["mapq"]
-        self.h_has_seq = d["has_seq"]
+        self.h_has_seq = d["has_seq"].astype(bool)
         self.h_qlen = np.where(self.h_has_seq, d["qlen"], 0).astype(np.int32)      # pysam query_length
         self.h_nm, self.h_name_id, self.h_n_cigar = d["nm"], d["name_id"], d["n_cigar"]
         self.h_sa_off = np.concatenate([[0], np.cumsum(d["sa_count"])]).astype(np.int64)
@@ -151,14 +198,12 @@ class DeviceRecords:
         else:
             mirrors = HostMirrors(rec) if (self.rank == 0) else None
         self.has_host = mirrors is not None
-        self._rec = rec                           # (tests: the CPU stand-ins of the kernels read the records from here)
-        self._rec_offset = self.lo if local_only else 0      # ordinal in the file of self._rec's first record
         if mirrors is not None:
             for k, v in vars(mirrors).items():
                 if k.startswith("h_"):
                     setattr(self, k, v)
             self.n_names = mirrors.n_names
-            self._names: Optional[List[str]] = mirrors._names
+            self._names: Optional[NameTable] = mirrors._names
             self._lazy_names = mirrors._lazy_names
             assert mirrors.n_total == self.n_total, "host mirrors do not describe the whole file"
             self.total_ops_all = int(self.h_n_cigar.astype(np.int64).sum())
@@ -172,18 +217,22 @@ class DeviceRecords:
             t = np.arange(len(self.header_chroms))
             self.tid_lo = np.searchsorted(mapped, t, side="left")
             self.tid_hi = np.searchsorted(mapped, t, side="right")
+            if dev.type == "cuda":
+                self.sa_device_arrays()          # part of loading the records, not of the first build on them
         else:
             # a rank that only serves kernels: no per-record host data at all
             self.h_nonacgt_rec = np.zeros(0, dtype=np.int64)
             self.h_nonacgt_pos = np.zeros(0, dtype=np.int32)
             self.h_tid = np.zeros(0, dtype=np.int32)
-            self.n_names, self._names, self._lazy_names = 0, [], None
+            self.n_names, self._names, self._lazy_names = 0, NameTable.from_list([]), None
             self.total_ops_all, self.n_sa = self.total_ops, 0
 
     @property
-    def names(self) -> List[str]:
+    def names(self) -> NameTable:
+        """Read names by name id: a sequence of ``str`` that keeps the bytes and makes strings on demand."""
         if self._names is None:
-            self._names = self._lazy_names.materialise_names()
+            self._names = self._lazy_names.name_table()
+            self._lazy_names = None
         return self._names
 
     def algorithmic_bytes(self) -> int:

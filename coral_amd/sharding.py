@@ -129,38 +129,45 @@ def build_graph_sharded(dr, seedfile, cn_seg, output_prefix=None, min_bp_support
 # ----------------------------------------------------------------------------------------------
 # input side: every rank decodes and uploads its own byte range of the BAM
 # ----------------------------------------------------------------------------------------------
-def _gather_bytes(dr, blob: bytes):
-    """Variable-length byte strings of all ranks on rank 0 (None elsewhere): sizes first, then one padded gather."""
+def _gather_to_rank0(dr, buf: np.ndarray):
+    """Variable-length uint8 buffers of all ranks on rank 0 (None elsewhere): the sizes first (one small all-gather), then ONE
+    gather of the buffers padded to the largest — only rank 0 receives (the other ranks have no use for the pieces)."""
     dev = _comm_device(dr)
-    n = torch.tensor([len(blob)], dtype=torch.int64, device=dev)
+    n = torch.tensor([len(buf)], dtype=torch.int64, device=dev)
     ns = [torch.zeros_like(n) for _ in range(dr.world)]
     dist.all_gather(ns, n, group=dr.group)
     ns = [int(x.item()) for x in ns]
-    nmax = max(max(ns), 1)
-    buf = torch.zeros(nmax, dtype=torch.uint8, device=dev)
-    if len(blob):
-        buf[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
-    outs = [torch.empty_like(buf) for _ in range(dr.world)] if dr.rank == 0 else None
-    if dist.get_backend(dr.group) == "gloo":
-        dist.gather(buf, outs, dst=0, group=dr.group)
-    else:                                     # RCCL: gather = all ranks send, rank 0 receives
-        all_outs = [torch.empty_like(buf) for _ in range(dr.world)]
-        dist.all_gather(all_outs, buf, group=dr.group)
-        outs = all_outs if dr.rank == 0 else None
+    nmax = max(max(ns), 8)
+    send = torch.zeros(nmax, dtype=torch.uint8, device=dev)
+    if len(buf):
+        send[:len(buf)] = torch.from_numpy(buf).to(dev)
+    outs = [torch.empty_like(send) for _ in range(dr.world)] if dr.rank == 0 else None
+    dist.gather(send, outs, dst=0, group=dr.group)
     if dr.rank != 0:
         return None
-    return [o[:k].cpu().numpy().tobytes() for o, k in zip(outs, ns)]
+    return [o[:k].cpu().numpy() for o, k in zip(outs, ns)]
+
+
+LAST_LOAD = {}      # timings of the last load_bam_sharded call on this rank (bench.py): decode, gather, merge seconds
 
 
 def load_bam_sharded(path: str, rank: int, world: int, device, group=None, n_threads=None):
     """Per-rank input: decode the rank's byte range of the BAM, upload only that shard, and gather — once — the per-record
     host fields and the read names to rank 0 (which unifies the range-local name ids).  Returns DeviceRecords; its host
-    mirrors describe the whole file on rank 0 and are absent elsewhere."""
-    import io
+    mirrors describe the whole file on rank 0 and are absent elsewhere.
+
+    What travels: per rank ONE buffer of fixed-width columns + one read-name blob + its offsets (``HostMirrors.pack``) — no
+    pickling, no text joins; rank 0 maps the columns in place and joins the name tables natively (``coral_names_unify``), so
+    names stay bytes until something asks for a ``str``."""
+    import time
     from . import bam
     from .records import DeviceRecords, HostMirrors
+    t0 = time.perf_counter()
     rec = bam.load_bam(path, device, n_threads=n_threads, rank=rank, world=world)
     stats = dict(bam.LAST_DECODE)
+    t1 = time.perf_counter()
+    LAST_LOAD.clear()
+    LAST_LOAD.update(decode_s=t1 - t0, gather_s=0.0, merge_s=0.0)
     if world == 1:
         dr = DeviceRecords(rec, device)
         dr.decode_stats = stats
@@ -170,27 +177,18 @@ def load_bam_sharded(path: str, rank: int, world: int, device, group=None, n_thr
         pass
     g = _G()
     g.rank, g.world, g.group, g.device = rank, world, group, torch.device(device)
-    piece = HostMirrors.piece_of(rec)
-    bio = io.BytesIO()
-    np.savez(bio, **{k: v for k, v in piece.items() if k != "n_names"})
-    pieces_raw = _gather_bytes(g, bio.getvalue())
-    names_raw = _gather_bytes(g, "\n".join(rec.names).encode())
+    raw = _gather_to_rank0(g, HostMirrors.pack(HostMirrors.piece_of(rec)))
     counts = torch.tensor([rec.n], dtype=torch.int64, device=_comm_device(g))
     all_counts = [torch.zeros_like(counts) for _ in range(world)]
     dist.all_gather(all_counts, counts, group=group)
     all_counts = [int(c.item()) for c in all_counts]
     lo = sum(all_counts[:rank])
+    t2 = time.perf_counter()
     host = None
     if rank == 0:
-        pieces, names = [], []
-        for raw, nraw in zip(pieces_raw, names_raw):
-            z = np.load(io.BytesIO(raw))
-            d = {k: z[k] for k in z.files}
-            local_names = nraw.decode().split("\n") if nraw else []
-            d["n_names"] = len(local_names)
-            pieces.append(d)
-            names.append(local_names)
-        host = HostMirrors.from_pieces(pieces, names)
+        host = HostMirrors.from_pieces([HostMirrors.unpack(r) for r in raw], n_threads=n_threads or bam.default_threads())
+    t3 = time.perf_counter()
+    LAST_LOAD.update(gather_s=t2 - t1, merge_s=t3 - t2)
     dr = DeviceRecords(rec, device, rank=rank, world=world, group=group, local_only=True, lo=lo, n_total=sum(all_counts), host=host)
     dr.decode_stats = stats
     return dr

@@ -325,6 +325,17 @@ class Records:
             self.names = ["read%08d" % int(x) for x in g]
         return self.names
 
+    def name_table(self):
+        """The names as ``coral_amd.names.NameTable`` (one byte blob + offsets): what a decoded BAM brings, and what synthetic
+        records build without a Python loop over the reads."""
+        from .names import NameTable
+        if isinstance(self.names, NameTable):
+            return self.names
+        if self.names is not None:
+            return NameTable.from_list(self.names)
+        t = NameTable.from_decimal("read", self.name_gid.cpu().numpy(), 8)
+        return t if t is not None else NameTable.from_list(self.materialise_names())
+
     def to(self, device) -> "Records":
         kw = {}
         for k, v in self.__dict__.items():

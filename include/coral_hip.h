@@ -241,6 +241,18 @@ int coral_cluster_first_fit(int64_t n, const int64_t *p1, const int64_t *p2, int
 int coral_first_seen_rows(int64_t n, int32_t ncols, const int64_t *rows, uint8_t *is_first);
 
 /* ------------------------------------------------------------------------------------------------
+ * coral_names_unify — HOST function: the read-name tables of `n_pieces` consecutive byte ranges of ONE BAM file (one per
+ * rank, each decoded on its own GPU; piece p has n_names[p] names as blob[p] + off[p][n_names[p] + 1], numbered in order of
+ * first appearance WITHIN the piece) -> the numbering a single decode of the whole file gives: name id = order of first
+ * appearance over the file = insertion order of the reference's dicts keyed by query_name
+ * (/root/reference/src/infer_breakpoint_graph.py:141-151).  lut[p][local id] receives the global id; out_blob (capacity:
+ * the pieces' blob bytes together) / out_off (capacity: Σ n_names + 1) the global table; *n_global its size.
+ * Exact: names are compared as bytes, a 64-bit hash only routes them; n_threads workers join hash partitions in parallel.
+ * ------------------------------------------------------------------------------------------------ */
+int coral_names_unify(int32_t n_pieces, const int64_t *n_names, const uint8_t *const *blob, const int64_t *const *off,
+                      int32_t *const *lut, uint8_t *out_blob, int64_t *out_off, int64_t *n_global, int32_t n_threads);
+
+/* ------------------------------------------------------------------------------------------------
  * coral_pyset_* — HOST functions: the iteration order of the Python sets of read names the reference builds and iterates
  * in its interval search (/root/reference/src/infer_breakpoint_graph.py:379-384 .add() per reached CN segment,
  * :405-419 `|=` unions, :428/432 iteration), obtained by replaying CPython 3.10's set algorithm on (item id, str hash)
@@ -302,8 +314,10 @@ int coral_reach_keys(void *handle, int64_t *codes, int32_t *counts);
  * Replaces pysam.AlignmentFile(path, 'rb') + the whole-file fetch() loop
  * (/root/reference/src/infer_breakpoint_graph.py:65, :140-158).  `open` inflates (n_threads zlib workers) and
  * parses the whole file; `sizes` reports {n_rec, n_cigar_words (padded), n_sa_rows, n_nonacgt, n_names,
- * names_bytes, n_ref, ref_names_bytes}; `fill` copies everything into caller-allocated arrays (names and
- * reference names as consecutive NUL-terminated strings); `close` frees the handle.
+ * names_bytes, n_ref, ref_names_bytes}; `fill` copies everything into caller-allocated arrays (read names as ONE blob of
+ * names_bytes bytes without terminators + name_off[n_names + 1], name id = order of first appearance in the file, i.e. the
+ * insertion order of the reference's dicts keyed by query_name, ibg:148-151; reference names as consecutive NUL-terminated
+ * strings); `close` frees the handle.
  * SA rows are 8 ints: ref id, 1-based pos, strand (0 '+', 1 '-'), leading S, M, +I/-D, trailing S, mapq
  * (leading S = -2 marks a CIGAR that contains S and M but is not one of the nine shapes of
  * cigar_parsing.py:219-229).  qlen is l_seq, or the CIGAR-implied query length when SEQ is '*'.
@@ -313,8 +327,8 @@ int coral_bam_decode_sizes(void *handle, int64_t sizes[8]);
 int coral_bam_decode_fill(void *handle, int32_t *tid, int32_t *pos, int32_t *end, int32_t *flag, int32_t *mapq,
                           int32_t *qlen, int32_t *has_seq, int32_t *nm, int32_t *name_id, int32_t *n_cigar,
                           int64_t *cigar_off, uint32_t *cigar, int64_t *sa_off, int32_t *sa, int32_t *sa_nm,
-                          int64_t *nonacgt_rec, int32_t *nonacgt_pos, char *names, char *ref_names,
-                          int32_t *ref_lens);
+                          int64_t *nonacgt_rec, int32_t *nonacgt_pos, char *names, int64_t *name_off,
+                          char *ref_names, int32_t *ref_lens);
 int coral_bam_decode_close(void *handle);
 /* The same for the rank-th of `world` byte ranges of the file (one process per GPU decodes only its share): the range starts
  * at the first BGZF block at or after its first byte and at the first record that starts in that block's inflated bytes or

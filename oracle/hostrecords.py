@@ -46,7 +46,7 @@ class HostRecords:
         self.n_cigar = g(rec.n_cigar).astype(np.int64)
         self.cigar_off = g(rec.cigar_off).astype(np.int64)
         self.cigar = g(rec.cigar).view(np.uint32)
-        self.names = rec.materialise_names()
+        self.names = list(rec.materialise_names())
         sa_off = g(rec.sa_off)
         sa = g(rec.sa)
         sa_nm = g(rec.sa_nm)

@@ -176,24 +176,43 @@ def install_cpu_kernel_fakes(monkeypatch):
     from oracle.hostrecords import HostRecords
     hosts = {}
 
+    class _LocalShard:
+        """What the record kernels of this process read: the product's own arrays of the local shard (coral_amd.records), as the
+        records object the oracle's HostRecords wraps.  Fields the record kernels never see (qlen, NM, names, SA) are empty."""
+
+        def __init__(self, dr):
+            g = lambda t: t.cpu().numpy()
+            self.n, self.header_chroms = dr.n, dr.header_chroms
+            self.tid, self.pos, self.end, self.n_cigar = g(dr.tid), g(dr.pos), g(dr.end), g(dr.n_cigar)
+            fm = g(dr.flagmq).astype(np.int64)
+            self.flag, self.mapq, self.has_seq = fm & 0xFFFF, (fm >> 16) & 0xFF, (fm >> 24) & 1
+            z = np.zeros(dr.n, dtype=np.int64)
+            self.qlen, self.nm, self.name_id = z, z, z
+            self.cigar_off, self.cigar = g(dr.cigar_off), g(dr.cigar)
+            self.sa_off, self.sa, self.sa_nm = np.zeros(dr.n + 1, dtype=np.int64), np.zeros((0, 8), dtype=np.int64), z[:0]
+            self.nonacgt_rec, self.nonacgt_pos = z[:0], z[:0]
+
+        def materialise_names(self):
+            return []
+
     def host_of(dr):
         if id(dr) not in hosts:
-            hosts[id(dr)] = HostRecords(dr._rec)
-        return hosts[id(dr)]
+            hosts[id(dr)] = (HostRecords(_LocalShard(dr)), dr)          # (dr kept alive: ids are not re-used meanwhile)
+        return hosts[id(dr)][0]
 
-    # The stand-ins replace only the LOCAL launches (records [dr.lo, dr.hi) of this process); the exchange and
-    # ordering code of coral_amd.kernels / coral_amd.sharding stays the product's own.
+    # The stand-ins replace only the LOCAL launches (records [dr.lo, dr.hi) of this process, ordinals local to the shard); the
+    # exchange and ordering code of coral_amd.kernels / coral_amd.sharding stays the product's own.
     def scan_local(dr, min_gap, min_mapq, gap_cap):
         h = host_of(dr)
         mb, qi, b0, b1, rows = [], [], [], [], []
-        for i in range(dr.lo - dr._rec_offset, dr.hi - dr._rec_offset):        # ordinals within dr._rec
+        for i in range(dr.n):
             bl = h.blocks(i)
             mb.append(sum(e - s for s, e in bl)); qi.append(h.infer_read_length(i) or 0)
             b0.append(bl[0][0] if bl else -1); b1.append(bl[-1][1] if bl else -1)
             if h.mapq[i] >= min_mapq:
                 for k in range(len(bl) - 1):
                     if abs(bl[k + 1][0] - bl[k][1]) > min_gap:
-                        rows.append((i + dr._rec_offset - dr.lo, k + 1, bl[k][1], bl[k + 1][0], b0[-1], b1[-1]))
+                        rows.append((i, k + 1, bl[k][1], bl[k + 1][0], b0[-1], b1[-1]))
         summary = torch.tensor([mb, qi, b0, b1], dtype=torch.int32).t().contiguous().reshape(-1, 4)
         return summary, lambda: torch.tensor(rows, dtype=torch.int64).reshape(-1, 6)
 
@@ -201,7 +220,7 @@ def install_cpu_kernel_fakes(monkeypatch):
         h = host_of(dr)
         out = torch.zeros((2, len(sg)), dtype=torch.int64)
         for j, (t, s, e) in enumerate(sg):
-            idx = [i for i in h.region(h.chroms[t], s, e) if dr.lo <= i + dr._rec_offset < dr.hi]
+            idx = h.region(h.chroms[t], s, e)
             out[0, j] = sum(1 for i in idx if h.infer_read_length(i))
             tot = 0
             for i in idx:
@@ -214,8 +233,7 @@ def install_cpu_kernel_fakes(monkeypatch):
         h = host_of(dr)
         keys = []
         for j, (t, p) in enumerate(uniq):
-            keys += [(j << 32) | (int(i) + dr._rec_offset - dr.lo) for i in h.region(h.chroms[t], p, p + 1)
-                     if dr.lo <= i + dr._rec_offset < dr.hi]
+            keys += [(j << 32) | int(i) for i in h.region(h.chroms[t], p, p + 1)]
         return torch.tensor(keys, dtype=torch.int64)
 
     def sa_table_local(dr):

@@ -26,7 +26,7 @@ def _run_ranks(world, case, tmp_path, extra=()):
     procs = []
     for rank in range(world):
         env = dict(os.environ, PYTHONHASHSEED="0", RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2" if world <= 3 else "1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_shard_worker.py"), case, str(tmp_path)] + list(extra),
                                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
@@ -34,7 +34,7 @@ def _run_ranks(world, case, tmp_path, extra=()):
         assert p.returncode == 0, o[-3000:]
 
 
-@pytest.mark.parametrize("case,world", [("tiny_edge", 2), ("small", 3)])
+@pytest.mark.parametrize("case,world", [("tiny_edge", 2), ("small", 3), ("small", 8)])
 def test_per_rank_bam_decode_equals_reference(case, world, golden_dir, tmp_path):
     """The input side of the N > 1 path: the test writes a BAM, every rank decodes only ITS byte range of it and keeps only
     that shard; rank 0 gets the gathered per-record host fields with unified read-name ids.  Same golden as everywhere."""
@@ -48,24 +48,16 @@ def test_per_rank_bam_decode_equals_reference(case, world, golden_dir, tmp_path)
     with open(tmp_path / "result.json") as fp:
         res = json.load(fp)
     assert res["normal_cov"] == gold["A2"]["normal_cov"]
-    assert 0 < res["shard"][1] < res["shard"][2] == gold["n_records"]
+    assert 0 < res["shard"][1] < res["shard"][2] == gold["n_records"] and res["world"] == world
     assert sorted(res["files"]) == sorted(gold["files"])
     for k in res["files"]:
         compare_graph_text(res["files"][k], gold["files"][k])
 
 
-@pytest.mark.parametrize("case", ["tiny_edge", "small"])
-def test_two_rank_shard_merge_equals_reference(case, golden_dir, tmp_path):
-    port = _free_port()
-    procs = []
-    for rank in range(2):
-        env = dict(os.environ, PYTHONHASHSEED="0", RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="2")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_shard_worker.py"), case, str(tmp_path)],
-                                      env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=600)[0] for p in procs]
-    for p, o in zip(procs, outs):
-        assert p.returncode == 0, o[-3000:]
+@pytest.mark.parametrize("case,world", [("tiny_edge", 2), ("small", 2), ("small", 8)])
+def test_shard_merge_equals_reference(case, world, golden_dir, tmp_path):
+    """Records already in memory, split over `world` ranks by CIGAR-op count (world 8 = one node's worth of ranks)."""
+    _run_ranks(world, case, tmp_path)
     with open(os.path.join(golden_dir, "e2e_%s.json" % case)) as fp:
         gold = json.load(fp)
     with open(tmp_path / "result.json") as fp:
