@@ -8,9 +8,12 @@ BreakpointGraph objects + *_graph.txt written (Gurobi cycle step skipped), i.e. 
 Prints ONE JSON line (rank 0) with
   `roofline`      dominant kernel (coral_cigar_scan), HIP-event timed on the launch stream inside the timed steps;
   `h2d_ms` / `value_incl_h2d`   pinned host -> HBM of the resident arrays, measured once, and the rate with it added;
-  `decode`        BGZF/BAM decode throughput of the product's GPU decoder (coral_bamgpu_*) on a BAM of --bam-reads reads of the same
-                  workload; `decode_host` the host pipeline (coral_bam_decode_*) on the same file;
-  `end_to_end`    BAM file -> graph files (decode of every rank's byte range + upload + build), same BAM;
+  `first_build_ms` / `value_cold`   the FIRST build of the process on fresh records (what one `CoRAL.py reconstruct` run pays: library
+                  load, first launches, pinned pools, every per-records one-off), before any warm-up; `value` is the steady state;
+  `decode`        BGZF/BAM decode throughput of the product's GPU decoder (coral_bamgpu_*) on a BAM FILE of the whole workload
+                  (--bam-reads 0 = the configuration's read count: 2 M reads, 18.7 GB at config 3); `decode_host` the host pipeline
+                  (coral_bam_decode_*) on the first tenth of the same file (a byte range; the whole file would take 17 s);
+  `end_to_end`    BAM file -> graph files (decode of every rank's byte range + gather / merge on rank 0 + build), same BAM;
   `cpu_baseline`  the CPU oracle on a bounded sample of the same workload, resident (`value`) and from its BAM (`end_to_end`).
 """
 import argparse
@@ -38,8 +41,9 @@ def main():
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--reads", type=int, default=0, help="override the read count of the config (0 = as configured)")
     ap.add_argument("--cpu-sample", type=int, default=50000, help="reads in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--bam-reads", type=int, default=200000,
-                    help="reads of the BAM the decode / end-to-end legs run on (same generator and layout; 0 = skip those legs)")
+    ap.add_argument("--bam-reads", type=int, default=0,
+                    help="reads of the BAM the decode / end-to-end legs run on (same generator and layout); 0 (default) = the "
+                         "configuration's own read count, i.e. the size the metric is quoted on; -1 = skip those legs")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of N > 1)")
     ap.add_argument("--shared-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--gc-policy", default="pause", choices=["pause", "freeze", "none"],
@@ -109,7 +113,8 @@ def main():
         dr = sharding.shard_records(rec, rank, world, dev)      # world == 1: all records on this GPU
         n_reads_total = cfg.n_reads
     alg_bytes_local = dr.algorithmic_bytes()
-    del rec
+    if not (rank == 0 and a.bam_reads == 0 and a.mode == "shard"):
+        rec = None                                                  # (rank 0 keeps the records: they become the BAM file of the legs below)
     torch.cuda.empty_cache()
 
     def step(i):
@@ -117,8 +122,18 @@ def main():
         b = sharding.build_graph_sharded(dr, seeds, cn, prefix if (rank == 0 or a.mode == "samples") else None, gc_policy=a.gc_policy)
         return b
 
+    # the FIRST build of this process, on records nothing has been built from yet: what a one-shot `reconstruct` run pays.  It is
+    # also the first of the W warm-up steps (with --warmup 0 it is an extra, untimed step).
     kernels.PROFILE["scan_ms"] = []
-    for i in range(a.warmup):
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    tf = time.perf_counter()
+    step(-1)
+    torch.cuda.synchronize()
+    first_build_ms = (time.perf_counter() - tf) * 1e3
+    first_phases = {k: round(v * 1e3, 1) for k, v in ibg.PHASE_SECONDS.items()}
+    for i in range(1, a.warmup):
         step(-1 - i)
     kernels.PROFILE["scan_ms"] = []
     if world > 1:
@@ -148,7 +163,8 @@ def main():
         tt = torch.tensor([h2d_ms], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         h2d_ms = float(tt.item())
-    legs = bam_legs(a, rank, world, dev, work) if (a.bam_reads and a.mode == "shard") else None
+    legs = bam_legs(a, rank, world, dev, work, rec) if (a.bam_reads >= 0 and a.mode == "shard") else None
+    rec = None
     b = b_last
 
     if rank == 0:
@@ -174,9 +190,15 @@ def main():
                        "phase_ms_median": {k: round(sorted(p.get(k, 0.0) for p in phases)[len(phases) // 2] * 1e3, 1)
                                            for k in (phases[-1] if phases else {})}},
             "roofline": {"bound": "hbm", "kernel": scan_kernel, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": pmc_traffic(cfg, world, scan_kernel), "launch_ms": scan_ms_avg,
+                         "frac": achieved / 8000.0, "traffic": pmc_traffic(cfg, world, _lib.lib().coral_version().decode()), "launch_ms": scan_ms_avg,
                          "algorithmic_bytes_per_launch": int(alg_bytes_local)},
         }
+        out["first_build_ms"] = round(first_build_ms, 1)
+        out["value_cold"] = n_reads_total / (first_build_ms * 1e-3)
+        out["config"]["first_build_phase_ms"] = first_phases
+        out["config"]["host_threads"] = {"build": "1 Python thread + %s look-ahead threads of the interval search" %
+                                         os.environ.get("CORAL_SEARCH_THREADS", "6"), "decode": "see decode.host_threads"}
+        out["config"]["library"] = _lib.lib().coral_version().decode()
         if h2d_ms is not None:
             out["h2d_ms"] = round(h2d_ms, 1)
             out["value_incl_h2d"] = n_reads_total / (ms_per_step * 1e-3 + h2d_ms * 1e-3)
@@ -270,30 +292,37 @@ def measure_h2d(dr):
     return total_ms
 
 
-def bam_legs(a, rank, world, dev, work):
-    """`decode` and `end_to_end` on a real BAM file of --bam-reads reads of the same workload (writing the full 2 M-read file
-    would take minutes and ~20 GB; the cap is stated in the output).  N > 1: every rank decodes and uploads only its byte
-    range of the file; the end-to-end time is barrier to barrier."""
+def bam_legs(a, rank, world, dev, work, rec=None):
+    """`decode`, `decode_host` and `end_to_end` on a real BAM FILE of the whole workload (default: the configuration's own read
+    count — 2 M reads, 18.7 GB at config 3, the size the metric is quoted on).  Rank 0 writes the file (``rec``: the records the
+    timed steps ran on, when the sizes agree) and times the whole-file decodes; then EVERY rank decodes only its byte range of it,
+    rank 0 merges the per-record host fields, and the graph is built: the end-to-end time is barrier to barrier."""
     import torch
     import torch.distributed as dist
     from coral_amd import bam, sharding, synth
-    # N > 1: a larger file (up to 4 x), so that every rank's byte range is still worth a decode and the end-to-end figure
-    # shows what per-rank decode does, not the fixed costs
-    cfg = synth.scaled_config(a.config, min(a.bam_reads * min(world, 4), synth.named_config(a.config).n_reads))
-    shared = os.path.join("/tmp", "coral_bench_bam_%s" % os.environ.get("MASTER_PORT", str(os.getpid())))
+    full = synth.named_config(a.config)
+    if a.reads:
+        full.n_reads = a.reads
+    n_bam = full.n_reads if a.bam_reads == 0 else min(a.bam_reads, full.n_reads)
+    cfg = synth.scaled_config(a.config, n_bam)
+    shared = os.path.join(os.environ.get("CORAL_BENCH_TMP", "/tmp"), "coral_bench_bam_%s" % os.environ.get("MASTER_PORT", str(os.getpid())))
     path = os.path.join(shared, "input.bam")
     cn, seeds = os.path.join(shared, "cn.bed"), os.path.join(shared, "seeds.bed")
     out = {}
     if rank == 0:
         os.makedirs(shared, exist_ok=True)
-        rec = synth.generate(cfg, dev, chunk_pieces=200000)
+        if rec is None or rec.n_names != cfg.n_reads:
+            rec = synth.generate(cfg, dev, chunk_pieces=200000)
         synth.write_cn_bed(cfg, cn)
         synth.write_seed_bed(cfg, seeds)
-        t0 = time.perf_counter()
-        bam.write_bam_native(rec.to("cpu"), path, seed=1)
-        write_s = time.perf_counter() - t0
+        rec_cpu = rec.to("cpu")
         n_records = rec.n
         del rec
+        torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        bam.write_bam_native(rec_cpu, path, seed=1)
+        write_s = time.perf_counter() - t0
+        del rec_cpu
         size = os.path.getsize(path)
         # the product's decoder: inflate + parse on the GPU (coral_bamgpu_*); twice, the better run counts (the first one
         # carries one-off costs of the process)
@@ -306,54 +335,73 @@ def bam_legs(a, rank, world, dev, work):
             runs.append((time.perf_counter() - t0, dict(bam.LAST_DECODE)))
             assert whole.n == n_records
             del whole
+            torch.cuda.empty_cache()
         dec_s, st = min(runs, key=lambda r: r[0])
         out["decode"] = {"reads_per_s": cfg.n_reads / dec_s, "where": "gpu", "host_threads": st["threads"],
                          "GB_per_s_compressed": size / dec_s / 1e9, "GB_per_s_inflated": st["uncompressed_bytes"] / dec_s / 1e9,
                          "seconds": round(dec_s, 3), "seconds_all_runs": [round(r[0], 3) for r in runs], "batches": st["batches"],
                          "stage_seconds": {k: round(st[k], 3) for k in ("read_seconds", "setup_seconds", "waited_for_file_seconds",
                                                                          "waited_for_gpu_seconds", "host_seconds")},
+                         # the file was written seconds ago: the decoder reads it from the page cache, not from the disk
+                         "file_in_page_cache": True, "n_reads": cfg.n_reads, "n_records": n_records,
                          "bam": "%d reads (%d records) of %s, %.2f GB BGZF (zlib level 1), written in %.1f s; one process, whole file" % (
                              cfg.n_reads, n_records, a.config, size / 1e9, write_s)}
-        # the host pipeline (coral_bam_decode_*: zlib inflate on all host threads this process may use), same file
+        # the host pipeline (coral_bam_decode_*: zlib inflate on all host threads this process may use): the first tenth of the
+        # same file as a byte range (the whole 2 M-read file takes it ~17 s; reads/s over the records of that range)
+        parts = 10 if cfg.n_reads >= 1000000 else 1
         t0 = time.perf_counter()
-        whole = bam.decode_bam(path)
+        part = bam.decode_bam(path, rank=0, world=parts)
         hdec_s = time.perf_counter() - t0
         hst = dict(bam.LAST_DECODE)
-        assert whole.n == n_records
-        del whole
-        out["decode_host"] = {"reads_per_s": cfg.n_reads / hdec_s, "threads": hst["threads"], "GB_per_s_inflated": hst["uncompressed_bytes"] / hdec_s / 1e9,
-                              "seconds": round(hdec_s, 2)}
+        out["decode_host"] = {"reads_per_s": part.n_names / hdec_s, "threads": hst["threads"],
+                              "GB_per_s_inflated": hst["uncompressed_bytes"] / hdec_s / 1e9, "seconds": round(hdec_s, 2),
+                              "sample": "byte range 1 of %d of the same file: %d records, %d read names" % (parts, part.n, part.n_names)}
+        del part
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     dr = sharding.load_bam_sharded(path, rank, world, dev)
+    torch.cuda.synchronize()
+    load = dict(sharding.LAST_LOAD)
     t1 = time.perf_counter()
     b = sharding.build_graph_sharded(dr, seeds, cn, os.path.join(shared, "e2e") if rank == 0 else None, gc_policy=a.gc_policy)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t2 = time.perf_counter()
+    if world > 1:          # the slowest rank's decode of its byte range
+        tt = torch.tensor([load["decode_s"]], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        load["decode_s_max_over_ranks"] = float(tt.item())
     if rank == 0:
-        out["end_to_end"] = {"reads_per_s": cfg.n_reads / (t2 - t0), "seconds": round(t2 - t0, 2), "load_s": round(t1 - t0, 2),
-                             "build_s": round(t2 - t1, 2), "n_gpus": world,
+        out["end_to_end"] = {"reads_per_s": cfg.n_reads / (t2 - t0), "seconds": round(t2 - t0, 3), "load_s": round(t1 - t0, 3),
+                             "build_s": round(t2 - t1, 3), "n_gpus": world, "n_reads": cfg.n_reads,
+                             "decode_s": round(load.get("decode_s_max_over_ranks", load["decode_s"]), 3),
+                             "gather_s": round(load["gather_s"], 3), "merge_s": round(load["merge_s"], 3), "file_in_page_cache": True,
                              "what": "BAM file -> GPU decode (every rank its byte range: compressed bytes over PCIe, inflate + parse in HBM) -> "
-                                     "graph files; first build of the process on these records (includes one-off warm-up of the build)"}
+                                     "per-record host fields + name blobs gathered to rank 0 and merged natively -> graph files; the build is "
+                                     "the first one on these records"}
         shutil.rmtree(shared, ignore_errors=True)
     return out if rank == 0 else None
 
 
-def pmc_traffic(cfg, world, kernel):
-    """HBM bytes per scan launch from the committed rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json) when they
-    were taken on exactly this workload on one GPU; counters cannot be collected from inside this process -> else None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fp:
-            p = json.load(fp)
-        if world == 1 and p["workload"] == cfg.name and p["n_reads"] == cfg.n_reads and p["scan_kernel"] == kernel:
-            return p["kernels"][p["scan_kernel"]]["hbm_bytes"]
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+def pmc_traffic(cfg, world, library_version):
+    """HBM bytes per scan launch from a committed rocprofv3 --pmc run (profiles/r*_pmc_traffic*.json, tools/pmc_traffic.sh) — served
+    only when it was taken on exactly this workload, on one GPU, with a library built from THIS coral_kernels.hip (the library's
+    version string carries the source's hash, and so does the profile): a figure measured on another kernel yields None.
+    Counters cannot be collected from inside this process."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json"))):
+        try:
+            with open(path) as fp:
+                p = json.load(fp)
+            if world == 1 and p["workload"] == cfg.name and p["n_reads"] == cfg.n_reads and p.get("library") == library_version:
+                best = p["kernels"][p["scan_kernel"]]["hbm_bytes"]
+        except (OSError, KeyError, ValueError, TypeError):
+            pass
+    return best
 
 
 def cpu_baseline(config, n_sample, work):

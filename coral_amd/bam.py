@@ -124,6 +124,10 @@ def decode_bam_gpu(path: str, device="cuda:0", n_threads: Optional[int] = None, 
         ws = torch.empty(int(ws_bytes.value) + 256, dtype=torch.uint8, device=dev)
         base = (ws.data_ptr() + 255) & ~255
         stream = torch.cuda.current_stream(dev).cuda_stream
+        # `ws` may be a recycled block of torch's caching allocator: that is ordered only against the allocating stream, while the
+        # decoder's feeder thread and its own streams start writing into the workspace at once.  Let whatever the current stream
+        # still has queued (possibly on the block's previous owner) finish first — once per decode.
+        torch.cuda.current_stream(dev).synchronize()
         fail = lambda what, rc: _lib.CoralHipError("%s(%s) failed (%d): %s" % (what, path, rc, L.coral_bam_last_error().decode()))
         rc = L.coral_bamgpu_start(h, base, int(ws_bytes.value))
         if rc != 0:

@@ -323,17 +323,33 @@ def cn_problem(g, normal_cov):
 
 
 def _independent_rows(A, tol=1e-9):
-    """Indices (ascending) of a maximal linearly independent subset of the rows of A (entries are 0 / ±1), by QR with column
-    pivoting of Aᵀ.  Redundant balance rows are consistent (right-hand side 0), so which independent subset is kept changes
-    nothing: the kept rows span the same constraint space."""
-    from scipy.linalg import qr
-    m = A.shape[0]
+    """Indices (ascending) of a maximal linearly independent subset of the rows of A (entries are 0 / ±1): the rows are taken in
+    order and a row is kept when it is not in the span of the rows kept so far (Gram-Schmidt against an orthonormal basis of that
+    span, re-orthogonalised once; a dependent 0 / ±1 row leaves a residual at rounding level, an independent one a residual of
+    order one).  Redundant balance rows are consistent (right-hand side 0), so which independent subset is kept changes
+    nothing: the kept rows span the same constraint space.  numpy only (a scipy import would cost the first build 85 ms)."""
+    m, n = A.shape
     if m == 0:
         return []
-    r, piv = qr(A.T.astype(np.float64), mode="r", pivoting=True)
-    d = np.abs(np.diag(r)) if r.ndim == 2 else np.abs(r[:1])
-    rank = int(np.count_nonzero(d > tol * max(1.0, float(d[0])))) if len(d) else 0
-    return sorted(piv[:rank].tolist())
+    Q = np.zeros((min(m, n), n))
+    keep = []
+    for i in range(m):
+        v = A[i].astype(np.float64)
+        norm = float(np.sqrt(v @ v))
+        if norm == 0.0:
+            continue
+        k = len(keep)
+        if k == Q.shape[0]:
+            break
+        if k:
+            B = Q[:k]
+            v = v - B.T @ (B @ v)
+            v = v - B.T @ (B @ v)
+        res = float(np.sqrt(v @ v))
+        if res > tol * max(1.0, norm) and res > 1e-7 * norm:
+            Q[k] = v / res
+            keep.append(i)
+    return keep
 
 
 def _newton_step(h, A, r, n, p):

@@ -5,6 +5,8 @@
 // offset, ballot + popcount compaction emits the rare candidates, and integer atomics (order-free,
 // hence bit-exact) reduce per-segment sums.
 #include <hip/hip_runtime.h>
+
+#include <mutex>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -36,7 +38,12 @@ static int hip_err(hipError_t e, const char *what) {
     return CORAL_ERR_HIP;
 }
 
-extern "C" const char *coral_version(void) { return "coral_hip 0.1 (gfx950)"; }
+// CORAL_KERNELS_SHA: first 16 hex digits of sha256(coral_kernels.hip), passed by the build (__graft_entry__.build): bench.py serves a
+// committed PMC traffic figure as `roofline.traffic` only when it was measured on a library built from this very source.
+#ifndef CORAL_KERNELS_SHA
+#define CORAL_KERNELS_SHA "unknown"
+#endif
+extern "C" const char *coral_version(void) { return "coral_hip 0.3 (gfx950) kernels:" CORAL_KERNELS_SHA; }
 extern "C" const char *coral_last_error(void) { return g_err; }
 // name of the kernel coral_cigar_scan launches, as rocprofv3 prints it (bench.py puts it next to the roofline figures)
 extern "C" const char *coral_scan_kernel_name(void);
@@ -313,8 +320,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cigar_scan_v4(
         const uint32_t lim = (room >> 31) != 0 ? 0x7fffffffu : (uint32_t)room;
         return lane_off < lim ? lane_off : lim;
     };
-    auto load = [&](int c) -> cquad_t {                          // compiler-tracked (exact path)
-        return __builtin_nontemporal_load(reinterpret_cast<const cquad_t *>(wave_src + (long long)c * (WAVE * 16) + lane_offset(c)));
+    auto load = [&](int c) -> cquad_t {                          // compiler-tracked (exact path: 0.1 % of the chunks).  A plain load, NOT
+        // non-temporal: only the ring's loads carry `nt`, which is how tools/check_scan_ring.py tells them apart in the disassembly
+        return *reinterpret_cast<const cquad_t *>(wave_src + (long long)c * (WAVE * 16) + lane_offset(c));
     };
 
     // ---- record cursor (metadata is wave-uniform: scalar loads, requested one record ahead); positions relative to `base`
@@ -540,12 +548,13 @@ extern "C" int coral_cigar_scan(const coral_records_t *rec, int32_t min_gap, int
     if (rec->n_rec == 0) return CORAL_OK;
     if (!summary || !gap_count || (gap_cap && !gaps)) return set_err(CORAL_ERR_ARG, "cigar_scan: null output");
     if ((((uintptr_t)gaps) & 15u) || (((uintptr_t)summary) & 15u)) return set_err(CORAL_ERR_ARG, "cigar_scan: summary and gaps must be 16-byte aligned");
-    if (g_ring == 0) {
+    static std::once_flag tuning_once;          // (the entry point is re-entrant: the overrides are read exactly once, by one thread)
+    std::call_once(tuning_once, [] {
         const char *a = getenv("CORAL_SCAN_RING"), *b = getenv("CORAL_SCAN_WG_PER_CU"), *c = getenv("CORAL_SCAN_GROUP");
-        g_ring = a ? atoi(a) : SCAN_RING_DEFAULT;
         g_wg_per_cu = b ? atoi(b) : 0;
         if (c && atoi(c) >= 1 && atoi(c) <= 64) g_group = atoi(c);
-    }
+        g_ring = a ? atoi(a) : SCAN_RING_DEFAULT;
+    });
 #define LAUNCH_V4(R)                                                                                                              \
     do {                                                                                                                          \
         const int blocks_ = scan_grid<R>(rec->n_rec);                                                                             \

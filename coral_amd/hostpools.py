@@ -1,8 +1,8 @@
 """Host BLAS thread pools and the graph build.
 
 The host side of the build is a single thread plus the few native search workers of coral_search_*; its only dense linear
-algebra is the CN assignment, systems of ~100 unknowns.  numpy and scipy each bring an OpenBLAS pool with one thread per core
-(64 on the MI355X hosts), and every multi-threaded BLAS call — or every change of the pool size — leaves those threads spinning
+algebra is the CN assignment, systems of ~100 unknowns.  numpy brings an OpenBLAS pool with one thread per core
+(64 on the MI355X hosts; the build itself no longer imports scipy), and every multi-threaded BLAS call — or every change of the pool size — leaves those threads spinning
 for a while.  That costs far more CPU time than the build itself, and under a container CPU quota (cgroup ``cpu.max``) it gets
 the whole process throttled for tens of milliseconds at a time (measured: 13 throttling events in 10 builds).  So the first
 build of a process sets the BLAS pools to ONE thread, for the rest of the process (flipping the size per build is exactly what
@@ -22,9 +22,8 @@ def apply_once():
     if _applied is not None:
         return
     n = int(os.environ.get("CORAL_HOST_THREADS", "1"))
-    if n <= 0:
-        _applied = False
+    if n <= 0 or os.environ.get("OPENBLAS_NUM_THREADS") == str(n):
+        _applied = False          # left alone on request, or the pools were created at that size already (bench.py, the CLI)
         return
-    import scipy.linalg                      # noqa: F401 — scipy ships its own OpenBLAS: it must be loaded to be limited
     from threadpoolctl import threadpool_limits
     _applied = threadpool_limits(limits=n, user_api="blas")

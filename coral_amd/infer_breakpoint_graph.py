@@ -89,10 +89,11 @@ class _ChimericAlignments(dict):
     ``__iter__``, so that ``dict(x)`` / ``x.copy()`` / ``{**x}`` take the generic route through ``keys()`` and
     ``__getitem__`` instead of copying the raw table."""
 
-    def __init__(self, owner, name_ids):
+    def __init__(self, owner, name_ids, keep=None):
         super().__init__()
         self._owner = weakref.proxy(owner)      # no reference cycle: the result is freed by reference counting, not by the GC
         self._name_ids = name_ids
+        self._keep = keep                       # owner of the memory `name_ids` is a view of
         self._names_ = None                     # read names in dict order
         self._index_ = None
         self._filled = False
@@ -417,8 +418,10 @@ class bam_to_breakpoint_nanopore():
         self.nm_stats = [mean, math.sqrt(s1 / T.n_mapq60_plain - mean ** 2), T.n_mapq60_plain]
         names = self.rec.names
         has = np.nonzero(T.read_length >= 0)[0]
-        self.read_length = _LazyReadLength(names, T.read_length, has)
-        self.chimeric_alignments = _ChimericAlignments(self, T.name_id)
+        # (T's host arrays are views of pinned staging buffers leased for T's lifetime: whatever outlives this object and still
+        # looks at one of them holds the staging too, or the buffer would go back to the pool under it)
+        self.read_length = _LazyReadLength(names, T.read_length, has, keep=T.staging)
+        self.chimeric_alignments = _ChimericAlignments(self, T.name_id, keep=T.staging)
         logging.info(_t() + "Fetched %d chimeric reads." % (len(self.chimeric_alignments)))
         logging.info(_t() + "Computed alignment intervals on all chimeric reads.")
 
@@ -1388,9 +1391,10 @@ class _LazyIndelAlignments(dict):
 class _LazyReadLength(dict):
     """``read name -> query length`` for reads with a primary record; built from arrays on first use."""
 
-    def __init__(self, names, rl, has):
+    def __init__(self, names, rl, has, keep=None):
         super().__init__()
         self._names, self._rl, self._has, self._done = names, rl, has, False
+        self._keep = keep                       # owner of the memory `rl` is a view of
 
     def _fill(self):
         if not self._done:

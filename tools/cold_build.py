@@ -35,8 +35,8 @@ rec = synth.generate(cfg, "cuda:0", chunk_pieces=200000)
 torch.cuda.synchronize()
 print("generated %d records of %s in %.1f s" % (rec.n, cfg.name, time.perf_counter() - t), flush=True)
 t = time.perf_counter()
-rec.materialise_names()
-print("materialise_names: %.3f s (synthetic input only: a decoded BAM brings its names)" % (time.perf_counter() - t), flush=True)
+rec.names = rec.name_table()
+print("name table (blob + offsets) of the synthetic reads: %.3f s (a decoded BAM brings it)" % (time.perf_counter() - t), flush=True)
 
 
 if os.environ.get("PRE_POOLS"):

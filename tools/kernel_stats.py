@@ -1,6 +1,7 @@
 """rocprofv3 --kernel-trace --stats output -> the markdown summary committed under profiles/ (libcoral_hip kernels only)."""
 import csv, glob, sys
 d, out_md, out_csv, cmd = sys.argv[1:5]
+alg_gb = float(sys.argv[6]) / 1e9 if len(sys.argv) > 6 else 16.044
 note = sys.argv[5] if len(sys.argv) > 5 else "config 3: 2,000,000 reads x 20 kb, 2,163,774 records, 3.99e9 CIGAR ops = 16.04 GB algorithmic bytes per scan launch"
 f = glob.glob(d + "/**/*_kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
@@ -14,7 +15,7 @@ with open(out_csv, "w") as fp:
     for r in ours:
         w.writerow(r)
 with open(out_md, "w") as fp:
-    fp.write("# rocprofv3 --kernel-trace --stats (round 2)\n\nCommand: `%s`\n" % cmd)
+    fp.write("# rocprofv3 --kernel-trace --stats (round 3)\n\nCommand: `%s`\n" % cmd)
     fp.write("(%s).\n\n" % note)
     fp.write("The run also contains the synthetic-data generator and hipcub/rocprim sorts: %d kernel rows, %.1f ms in total.\n" % (len(rows), total))
     fp.write("Kernels of libcoral_hip.so:\n\n| kernel | calls | total ms | avg ms | min ms | max ms |\n|---|---|---|---|---|---|\n")
@@ -31,6 +32,7 @@ with open(out_md, "w") as fp:
                     dur.append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e6)
         full = [x for x in dur if x >= 0.5 * max(dur)] if dur else [float(scan[0]["AverageNs"]) / 1e6]
         a = sum(full) / len(full)
-        fp.write("\n`%s`: %d launches over the full workload, average %.3f ms for 16.044 GB => %.2f TB/s under the profiler (bench.py's own HIP-event "
-                 "figure of the same run is in the BENCH line below).\n" % (scan[0]["Name"].split("(")[0].replace("void ", ""), len(full), a, 16.044 / a))
+        fp.write("\n`%s`: %d launches over the full workload, average %.3f ms for %.3f GB algorithmic => %.2f TB/s = %.3f of the 8 TB/s HBM peak under the "
+                 "profiler (bench.py's own HIP-event figure of the same run: roofline.launch_ms of the line).\n" % (
+                     scan[0]["Name"].split("(")[0].replace("void ", ""), len(full), a, alg_gb, alg_gb / a, alg_gb / a / 8.0))
 print(open(out_md).read())

@@ -5,6 +5,8 @@ FETCH_SIZE reports half of the bytes of a wide coalesced streaming read, so it i
 import collections, csv, glob, json, sys
 
 fetch_dir, write_dir, n_reads, records, alg_bytes, out_json, out_md = sys.argv[1:8]
+workload = sys.argv[8] if len(sys.argv) > 8 else "cfg3"
+library = sys.argv[9] if len(sys.argv) > 9 else None          # coral_version(): carries the hash of coral_kernels.hip
 
 
 def collect(d, counter):
@@ -37,14 +39,14 @@ for k in sorted(F):
     kernels[k] = dict(launches=len(F[k]), fetch_kib=f, write_kib=w, hbm_bytes=2 * f * 1024 + w * 1024,
                       avg_ns_under_pmc=sum(D[k]) / len(D[k]) if k in D else None)
 scan = [k for k in kernels if k.startswith("k_cigar_scan")]
-doc = dict(workload="cfg3", n_reads=int(n_reads), records=int(records), algorithmic_bytes_per_scan_launch=int(alg_bytes),
+doc = dict(workload=workload, library=library, n_reads=int(n_reads), records=int(records), algorithmic_bytes_per_scan_launch=int(alg_bytes),
            scan_kernel=scan[0] if scan else None, kernels=kernels,
            method="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (with --kernel-trace only); "
                   "hbm_bytes = 2 * FETCH_SIZE KiB * 1024 + WRITE_SIZE KiB * 1024 (gfx950 FETCH_SIZE halves wide streaming reads)")
 json.dump(doc, open(out_json, "w"), indent=1)
 with open(out_md, "w") as fp:
     fp.write("# PMC traffic — rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes with --kernel-trace only\n")
-    fp.write("Target: `python tools/pmc_target.py` (config 3: %s reads, %s records, algorithmic bytes per scan launch %s).\n" % (n_reads, records, alg_bytes))
+    fp.write("Target: `python tools/pmc_target.py %s %s` (%s reads, %s records, algorithmic bytes per scan launch %s); library `%s`.\n" % (n_reads, workload, n_reads, records, alg_bytes, library))
     fp.write("FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled (gfx950 counts 128-B streaming requests as 64 B), WRITE_SIZE is exact.\n\n")
     fp.write("| kernel | launches | FETCH_SIZE KiB (avg) | WRITE_SIZE KiB (avg) | HBM bytes / launch | avg ns (under PMC) |\n|---|---|---|---|---|---|\n")
     for k, v in kernels.items():
