@@ -104,6 +104,7 @@ def main():
 
     t0 = time.time()
     rec = synth.generate(cfg, dev, chunk_pieces=200000)
+    rec.names = rec.name_table()              # input construction: a decoded BAM brings its read names (blob + offsets) with it
     torch.cuda.synchronize()
     gen_s = time.time() - t0
     if a.mode == "samples" and world > 1:

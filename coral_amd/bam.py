@@ -209,20 +209,42 @@ def _reg2bin(beg: int, end: int) -> int:
     return 0
 
 
-def _bgzf_blocks(data: bytes, level: int = 1):
-    for i in range(0, len(data), 0xff00):
-        chunk = data[i:i + 0xff00]
+_BGZF_EMPTY = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")      # 28 bytes; at the end: the EOF marker
+
+
+def _bgzf_blocks(data: bytes, level: int = 1, block_size: int = 0xff00, empty_block_every: int = 0):
+    """BGZF blocks of ``data`` (``block_size`` payload bytes each, at most 0xff00) + the EOF marker.  ``empty_block_every`` = k:
+    an empty block (the 28 bytes of the EOF marker, legal anywhere in a BGZF stream) after every k-th data block."""
+    assert 0 < block_size <= 0xff00
+    for n, i in enumerate(range(0, len(data), block_size)):
+        chunk = data[i:i + block_size]
         co = zlib.compressobj(level, zlib.DEFLATED, -15)
         comp = co.compress(chunk) + co.flush()
         bsize = len(comp) + 25
         yield (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + comp +
                struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
-    yield bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")      # BGZF EOF marker
+        if empty_block_every and (n + 1) % empty_block_every == 0:
+            yield _BGZF_EMPTY
+    yield _BGZF_EMPTY      # BGZF EOF marker
 
 
-def write_bam(rec: Records, path: str, seed: int = 0, long_cigar_as_cg: bool = True, fast_seq: bool = False) -> None:
+_NM_PACK = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I"}
+
+
+def write_bam(rec: Records, path: str, seed: int = 0, long_cigar_as_cg: bool = True, fast_seq: bool = False, *, aux=None,
+              nm_type="i", with_qual: bool = False, block_size: int = 0xff00, empty_block_every: int = 0,
+              header_comment: str = "") -> None:
     """Serialise ``rec`` as a coordinate-sorted BAM (SEQ = deterministic ACGT with N at the listed non-ACGT
-    positions, QUAL absent, tags NM:i and SA:Z; CIGARs with more than 65535 ops go to the CG:B,I tag)."""
+    positions, QUAL absent, tags NM:i and SA:Z; CIGARs with more than 65535 ops go to the CG:B,I tag).
+
+    Options for files shaped like what aligners and htslib really write (tests of the decoders):
+      ``aux(i)``        -> (raw tag bytes in FRONT of NM, raw tag bytes BEHIND the last tag) of record i: any SAM aux tags;
+      ``nm_type``       one of c C s S i I (htslib stores integers in the smallest type that fits), None (no NM tag), or a
+                        callable i -> one of these;
+      ``with_qual``     real QUAL bytes (a hash of the position, 0..60) instead of 0xff;
+      ``block_size``    payload bytes per BGZF block (small: header, records and tags straddle blocks);
+      ``empty_block_every``  an empty BGZF block after every k-th block;
+      ``header_comment``     extra @CO text (a long header spans several BGZF blocks)."""
     g = lambda x: x.cpu().numpy()
     tid, pos, flag, mapq, qlen, has_seq, nm, name_id, n_cigar = (g(getattr(rec, k)) for k in
                                                                 ("tid", "pos", "flag", "mapq", "qlen", "has_seq", "nm", "name_id", "n_cigar"))
@@ -234,6 +256,8 @@ def write_bam(rec: Records, path: str, seed: int = 0, long_cigar_as_cg: bool = T
         na.setdefault(int(r), []).append(int(p))
     out = bytearray()
     text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (c, l) for c, l in zip(rec.header_chroms, rec.header_lens))
+    if header_comment:
+        text += "".join("@CO\t%s\n" % line for line in header_comment.split("\n"))
     out += b"BAM\x01" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(rec.header_chroms))
     for c, l in zip(rec.header_chroms, rec.header_lens):
         out += struct.pack("<i", len(c) + 1) + c.encode() + b"\0" + struct.pack("<i", l)
@@ -264,7 +288,9 @@ def write_bam(rec: Records, path: str, seed: int = 0, long_cigar_as_cg: bool = T
             if l_seq & 1:
                 code = np.append(code, 0)
             seq_bytes = ((code[0::2] << 4) | code[1::2]).astype(np.uint8).tobytes()
-        tags = b"NMi" + struct.pack("<i", int(nm[i]))
+        front, behind = aux(i) if aux is not None else (b"", b"")
+        ty = nm_type(i) if callable(nm_type) else nm_type
+        tags = front + (b"NM" + ty.encode() + struct.pack(_NM_PACK[ty], int(nm[i])) if ty is not None else b"")
         if i in getattr(rec, "sa_text", {}):            # tests: verbatim SA text (odd CIGAR shapes)
             tags += b"SAZ" + rec.sa_text[i].encode() + b"\0"
         elif sa_off[i + 1] > sa_off[i]:
@@ -278,8 +304,13 @@ def write_bam(rec: Records, path: str, seed: int = 0, long_cigar_as_cg: bool = T
         name = names[name_id[i]].encode() + b"\0"
         body = struct.pack("<iiBBHHHiiii", int(tid[i]), int(pos[i]), len(name), int(mapq[i]),
                            _reg2bin(int(pos[i]), int(pos[i]) + max(1, rlen)), len(cig_field), int(flag[i]), l_seq, -1, -1, 0)
-        body += name + cig_field.astype("<u4").tobytes() + seq_bytes + b"\xff" * l_seq + tags
+        if with_qual and l_seq:
+            qual_bytes = ((hash_u32(seed, S_SEQ, torch.arange(l_seq, dtype=torch.int64) + (i + 7) * (1 << 22)) % 61).numpy()
+                          .astype(np.uint8).tobytes())
+        else:
+            qual_bytes = b"\xff" * l_seq
+        body += name + cig_field.astype("<u4").tobytes() + seq_bytes + qual_bytes + tags + behind
         out += struct.pack("<i", len(body)) + body
     with open(path, "wb") as fp:
-        for blk in _bgzf_blocks(bytes(out)):
+        for blk in _bgzf_blocks(bytes(out), block_size=block_size, empty_block_every=empty_block_every):
             fp.write(blk)

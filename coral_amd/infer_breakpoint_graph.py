@@ -396,11 +396,16 @@ class bam_to_breakpoint_nanopore():
         """Issue the two passes that depend on the records alone before any host logic runs: the fused CIGAR scan (launched
         without waiting for it) and, on a stream of their own, the SA table + pair table (K3, K4), whose host round trips then
         overlap with the scan.  What fetch() would raise is kept and raised there."""
+        trace = os.environ.get("CORAL_TRACE_OPEN") == "1"
+        t0 = time.perf_counter()
         self.scan()
+        t1 = time.perf_counter()
         try:
             self._chim_early = build_chimeric_table(self.rec)
         except Exception as exc:                      # noqa: BLE001 — re-raised by fetch(), where the reference raises
             self._chim_early = exc
+        if trace:
+            sys.stderr.write("launch_record_kernels: scan issue %.1f ms, chimeric table %.1f ms\n" % ((t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3))
 
     def fetch(self):
         """Collect chimeric alignments of every read from the SA tags (ibg:139-174)."""

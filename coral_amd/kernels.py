@@ -314,6 +314,16 @@ def _sa_table_local(dr):
 
 
 def _sa_table_on_current_stream(dr, d):
+    import os
+    import sys
+    import time
+    trace = os.environ.get("CORAL_TRACE_OPEN") == "1"
+    tt = [time.perf_counter()]
+
+    def lap(what):
+        if trace:
+            tt.append(time.perf_counter())
+            sys.stderr.write("  sa_table: %-22s %.1f ms\n" % (what, (tt[-1] - tt[-2]) * 1e3))
     L = _lib.lib()
     dev = dr.device
     n_sa = dr.n_sa
@@ -334,6 +344,7 @@ def _sa_table_on_current_stream(dr, d):
             ws_bytes = (int(counts[0]) + 1) << 20
             continue
         break
+    lap("coral_sa_table")
     if rc == -4:
         raise KeyError("SA CIGAR shape outside SM/MS/SMS/SMD/MDS/SMDS/SMI/MIS/SMIS")        # cp:255
     if rc == -5:
@@ -342,14 +353,18 @@ def _sa_table_on_current_stream(dr, d):
         raise _lib.CoralHipError("coral_sa_table failed (%d): %s" % (rc, L.coral_sa_last_error().decode()))
     n_reads, n_rows = int(counts[0]), int(counts[1])
     pairs = pair_table(dr, out_off, out_rows, n_reads, n_rows)
+    lap("pair table issue")
     # the rows leave the GPU column by column (transposed and widened there): the host wants seven contiguous int64 columns,
     # and cutting them out of a row-major [n, 8] array costs more than the whole kernel
     st = Staged(dr)
     h = st.start("table", dict(cols=out_rows[:n_rows].t().contiguous().to(torch.int64), off=out_off[:n_reads + 1].to(torch.int64),
                                name=out_name[:n_reads].to(torch.int64), failed=out_failed[:n_reads].to(torch.bool),
                                rl=out_rl[:dr.n_names].to(torch.int64)))
+    lap("staged copy: table")
     hp = st.start("pairs", dict(pairs=pairs[:2 * n_rows]))
+    lap("staged copy: pairs")
     st.wait("table")
+    lap("wait for the table")
     return h["cols"], h["off"], h["name"], h["failed"], h["rl"], hp["pairs"], out_rows[:n_rows], st
 
 

@@ -170,3 +170,74 @@ def test_count_distinct3():
     for n in (0, 1, 7, 5000):
         a, b, c = (rng.integers(0, 40, n).astype(np.int64) for _ in range(3))
         assert P.count_distinct3(a, b, c) == len(set(zip(a.tolist(), b.tolist(), c.tolist())))
+
+
+# ---- INTEGRATION.md must not drift from the header -------------------------------------------------
+def _split_args(text):
+    """Top-level comma split of a call's / prototype's argument text (nested parentheses and brackets respected)."""
+    out, depth, cur = [], 0, ""
+    for ch in text:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _calls(text, pattern):
+    """(name, argument text) of every `pattern`(...) in text, with balanced parentheses."""
+    for m in re.finditer(pattern, text):
+        i, depth = m.end(), 1
+        while depth and i < len(text):
+            depth += {"(": 1, ")": -1}.get(text[i], 0)
+            i += 1
+        yield m.group(1), text[m.end():i - 1]
+
+
+def header_prototypes():
+    text = open(os.path.join(ROOT, "include", "coral_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for name, args in _calls(text, r"\b(coral_[a-z0-9_]+)\s*\("):
+        a = _split_args(args)
+        protos[name] = 0 if a == ["void"] else len(a)
+    return protos
+
+
+def test_integration_md_calls_match_the_header():
+    """Every `L.coral_*(...)` call printed in INTEGRATION.md §2 has exactly as many arguments as the header's prototype (a call
+    shown with `...` is an explicit pointer to the header and only has to name an existing entry point)."""
+    protos = header_prototypes()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    doc = "\n".join(line.split("  #")[0] if "L.coral_" in line or line.startswith(" ") else line for line in doc.splitlines())
+    seen = 0
+    for name, args in _calls(doc, r"\bL\.(coral_[a-z0-9_]+)\("):
+        assert name in protos, "INTEGRATION.md calls %s, which include/coral_hip.h does not declare" % name
+        if args.strip() in ("...", "h, *array_pointers"):
+            continue
+        n = len(_split_args(re.sub(r"#[^\n]*", "", args)))
+        assert n == protos[name], "INTEGRATION.md calls %s with %d arguments, the header declares %d" % (name, n, protos[name])
+        seen += 1
+    assert seen >= 20
+    assert "MAX_SEGS" not in doc
+
+
+def test_ctypes_binding_matches_the_header():
+    """coral_amd/_lib.py: every argtypes list is as long as the header's prototype."""
+    from coral_amd import _lib
+    L = _lib.lib()
+    protos = header_prototypes()
+    checked = 0
+    for name, n in protos.items():
+        f = getattr(L, name)
+        if f.argtypes is not None:
+            assert len(f.argtypes) == n, "%s: _lib.py binds %d arguments, the header declares %d" % (name, len(f.argtypes), n)
+            checked += 1
+    assert checked >= 30
