@@ -61,6 +61,10 @@ def lib():
     L.coral_search_prefetch.restype = C.c_int
     L.coral_search_params.argtypes = [C.c_void_p, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_int32]
     L.coral_search_params.restype = C.c_int
+    L.coral_search_bfs.argtypes = [C.c_void_p, C.c_int32, P, P, P, P, P, C.c_double, C.c_int64, C.c_int32]
+    L.coral_search_bfs.restype = C.c_int
+    L.coral_search_bfs_get.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.coral_search_bfs_get.restype = C.c_int
     L.coral_search_within.argtypes = [C.c_void_p, C.c_int32, P, P, P]
     L.coral_search_within.restype = C.c_int
     L.coral_search_between.argtypes = [C.c_void_p, C.c_int64, P] + [C.c_int64] * 6

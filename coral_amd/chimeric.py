@@ -217,6 +217,31 @@ class PairSearch:
         self._check(self._L.coral_search_step(self._h, int(tid), int(s), int(e), int(si), int(ei)), "coral_search_step")
         return self._result(want_orders)
 
+    def bfs(self, seeds, seg_cn, seg_ix, chr_rank, tid_has_rows, cn_gain, interval_delta, log_level):
+        """The whole interval search in one native call (coral_search_bfs).  ``seeds`` int64 [n, 4] = contig id, start, end, ccid.
+        Returns {which: numpy array} of coral_search_bfs_get (copies) — see include/coral_hip.h."""
+        C = self._C
+        i64, f64 = (lambda a: np.ascontiguousarray(a, dtype=np.int64)), (lambda a: np.ascontiguousarray(a, dtype=np.float64))
+        seeds, seg_cn, seg_ix = i64(seeds).reshape(-1, 4), f64(seg_cn), i64(seg_ix)
+        chr_rank, has = np.ascontiguousarray(chr_rank, dtype=np.int32), np.ascontiguousarray(tid_has_rows, dtype=np.uint8)
+        if len(seg_cn) == 0:
+            seg_cn, seg_ix = np.zeros(1), np.zeros(1, dtype=np.int64)
+        rc = self._L.coral_search_bfs(self._h, len(seeds), seeds.ctypes.data, seg_cn.ctypes.data, seg_ix.ctypes.data, chr_rank.ctypes.data,
+                                      has.ctypes.data, float(cn_gain), int(interval_delta), int(log_level))
+        if rc in (-10, -11):
+            raise KeyError(self._L.coral_search_error(self._h).decode())
+        if rc == -12:
+            raise IndexError("list index out of range")
+        self._check(rc, "coral_search_bfs")
+        out = {}
+        for which in range(12):
+            ptr, n = C.c_void_p(), C.c_int64(0)
+            self._lib.check(self._L.coral_search_bfs_get(self._h, which, C.byref(ptr), C.byref(n)), "coral_search_bfs_get")
+            ty = C.c_double if which == 3 else C.c_int64
+            out[which] = (np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ty)), shape=(n.value,)).copy() if n.value else
+                          np.zeros(0, dtype=np.float64 if which == 3 else np.int64))
+        return out
+
     def within(self, intervals) -> Candidates:
         """alignment2bp_l (bu:129-186) of every chimeric read, dict order, against [(tid, start, end)]."""
         iv = np.ascontiguousarray(np.asarray(intervals, dtype=np.int64).reshape(-1, 3).T)

@@ -119,7 +119,10 @@ struct KeyHash {
     }
 };
 
+struct BfsOut;
+
 struct Search {
+    std::shared_ptr<BfsOut> bfs;                          // result of the last coral_search_bfs
     int64_t n_reads = 0, n_rows = 0, n_ent = 0;
     const int64_t *off = nullptr, *row_read = nullptr, *read_hash = nullptr, *read_name = nullptr, *e_key = nullptr, *e_row = nullptr;
     const int32_t *pairs = nullptr;                       // [2 * n_rows][8]  (k_bp_pairs)
@@ -425,6 +428,350 @@ void worker_main(Search *S) {
         e->cv.notify_all();
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// The whole interval search (find_amplicon_intervals' loop over the seeds + find_interval_i, ibg:343-673) on index arrays:
+// the order-dependent half — addbp (ibg:326-340), the inside / outside refinement of the target intervals (ibg:459-612),
+// interval_exclusive and the connection bookkeeping (ibg:614-673) — next to the pure steps above, so that a build makes ONE
+// native call for the search instead of one round trip per interval.  Every quirk of the reference the Python host logic
+// reproduced is reproduced here (Q2 the comparison result stored in `l`, Q3 the CN value used as a
+// truth value, Q5 the and / or precedence, Q9, Q10, Q13; exceptions swallowed by the reference's try / except leave the
+// same partial state).  Containers whose ITERATION ORDER is observable are replayed: the `hit` set of interval_exclusive is
+// a CPython set of small ints (PySetEmu with hash(i) = i), dict key order = first insertion.
+// ---------------------------------------------------------------------------------------------
+struct BfsBp {
+    int64_t f[11];                                       // c1 p1 o1 c2 p2 o2 head-name-id i j gap swapped
+    double stats[6];
+    int32_t flags;
+    int64_t ccid;
+    std::vector<std::array<int64_t, 2>> chunks;          // [begin, end) into chunk_read / chunk_i / chunk_j
+};
+
+struct BfsOut {
+    std::vector<int64_t> iv;                             // [n][5]: tid, s, e, ccid, s-is-a-bool (Q2)
+    std::vector<BfsBp> bps;
+    std::vector<int64_t> chunk_read, chunk_i, chunk_j;
+    std::vector<std::array<int64_t, 2>> conn_key;        // insertion order
+    std::vector<std::vector<int64_t>> conn_val;          // adds in order (duplicates kept: a set on the Python side)
+    std::vector<int64_t> events;                         // [n][6]
+    // flattened for retrieval
+    std::vector<int64_t> bp_flat, bp_meta, chunk_off, conn_flat, conn_off, conn_vals;
+    std::vector<double> bp_stats;
+    int64_t err_tid = -1;
+};
+
+struct BfsParams {
+    const double *seg_cn;
+    const int64_t *seg_ix;
+    const int32_t *chr_rank;
+    const uint8_t *tid_has_rows;
+    double cn_gain;
+    int64_t D;
+    bool log_events, log_debug;
+};
+
+enum { BFS_ERR_KEY_CHROM = -10, BFS_ERR_KEY_CHRIDX = -11, BFS_ERR_INDEX = -12 };
+
+struct BfsRun {
+    Search &S;
+    const BfsParams &P;
+    BfsOut &O;
+    BfsRun(Search &s, const BfsParams &p, BfsOut &o) : S(s), P(p), O(o) {}
+
+    int64_t nseg(int64_t t) const { return S.seg_off[t + 1] - S.seg_off[t]; }
+    int64_t sstart(int64_t t, int64_t k) const { return S.seg_start[S.seg_off[t] + k]; }
+    int64_t send(int64_t t, int64_t k) const { return S.seg_end[S.seg_off[t] + k]; }
+    double scn(int64_t t, int64_t k) const { return P.seg_cn[S.seg_off[t] + k]; }
+    // pos2cni(chr, pos)[0]: index (the reference's per-chromosome idx, Q8) of the first CN segment, in file order, containing pos;
+    // -1 = empty list, -2 = the chromosome has no CN segments at all (KeyError on cns_tree[chr])
+    int64_t pos2cni(int64_t t, int64_t pos) const {
+        if (t < 0 || t >= S.n_tid || nseg(t) == 0) return -2;
+        const int64_t n = nseg(t), *st = S.seg_start + S.seg_off[t], *en = S.seg_end + S.seg_off[t];
+        for (int64_t k = 0; k < n; ++k)
+            if (st[k] <= pos && pos <= en[k]) return P.seg_ix[S.seg_off[t] + k];
+        return -1;
+    }
+    bool pos2cni_any(int64_t t, int64_t pos) const { return pos2cni(t, pos) >= 0; }
+    void event(int64_t ty, int64_t a = 0, int64_t b = 0, int64_t c = 0, int64_t d = 0, int64_t e = 0) {
+        if (!P.log_events) return;
+        const int64_t row[6] = {ty, a, b, c, d, e};
+        O.events.insert(O.events.end(), row, row + 6);
+    }
+    static bool overlap(int64_t at, int64_t a1, int64_t a2, int64_t bt, int64_t b1, int64_t b2) {
+        return at == bt && a1 <= b2 && b1 <= a2;             // interval_overlap (bu:11-15)
+    }
+    int64_t conn_index(int64_t a, int64_t b, bool create) {
+        for (size_t k = 0; k < O.conn_key.size(); ++k)
+            if (O.conn_key[k][0] == a && O.conn_key[k][1] == b) return (int64_t)k;
+        if (!create) return -1;
+        O.conn_key.push_back({a, b});
+        O.conn_val.emplace_back();
+        return (int64_t)O.conn_key.size() - 1;
+    }
+    void conn_add(int64_t a, int64_t b, int64_t k) {         // conn.setdefault((min, max), set()).add(k)
+        const int64_t lo = a < b ? a : b, hi = a < b ? b : a;
+        O.conn_val[(size_t)conn_index(lo, hi, true)].push_back(k);
+    }
+
+    int enqueue(int64_t idx) {                               // _prefetch_step
+        const int64_t t = O.iv[5 * idx], s = O.iv[5 * idx + 1], e = O.iv[5 * idx + 2];
+        const int64_t si = pos2cni(t, s), ei = pos2cni(t, e);
+        if (si < 0 || ei < 0) return CORAL_OK;
+        if (!P.tid_has_rows[t]) return CORAL_OK;
+        return coral_search_prefetch(&S, t, s, e, si, ei);
+    }
+
+    // addbp (ibg:326-340): merge into the first breakpoint with the same ends within 200 bp, else append
+    int64_t addbp(const int64_t f[11], const double stats[6], int32_t flags, int64_t ccid, const std::array<int64_t, 2> &chunk) {
+        for (size_t k = 0; k < O.bps.size(); ++k) {
+            const int64_t *b = O.bps[k].f;
+            if (b[0] == f[0] && b[3] == f[3] && b[2] == f[2] && b[5] == f[5] && llabs(b[1] - f[1]) < 200 && llabs(b[4] - f[4]) < 200) {
+                O.bps[k].chunks.push_back(chunk);
+                return (int64_t)k;
+            }
+        }
+        BfsBp nb;
+        memcpy(nb.f, f, sizeof(nb.f));
+        memcpy(nb.stats, stats, sizeof(nb.stats));
+        nb.flags = flags;
+        nb.ccid = ccid;
+        nb.chunks.push_back(chunk);
+        O.bps.push_back(std::move(nb));
+        return (int64_t)O.bps.size() - 1;
+    }
+
+    int bfs_from(int64_t ai, int64_t ccid) {
+        const int64_t half = (int64_t)((double)S.max_seq_len / 2.0);
+        const int64_t D = P.D;
+        const double gain = P.cn_gain;
+        std::deque<int64_t> queue{ai};
+        while (!queue.empty()) {
+            const int64_t cur = queue.front();
+            queue.pop_front();
+            const int64_t tid = O.iv[5 * cur], s = O.iv[5 * cur + 1], e = O.iv[5 * cur + 2];
+            if (O.iv[5 * cur + 3] == -1) O.iv[5 * cur + 3] = ccid;
+            event(0, cur, tid, s, e, O.iv[5 * cur + 3]);
+            // ---- _search_step
+            const int64_t si = pos2cni(tid, s), ei = pos2cni(tid, e);
+            if (si < 0 || ei < 0) continue;
+            if (!P.tid_has_rows[tid]) { O.err_tid = tid; return BFS_ERR_KEY_CHROM; }
+            int rc = coral_search_step(&S, tid, s, e, si, ei);
+            if (rc != CORAL_OK) return rc;
+            std::shared_ptr<Entry> hold = S.current_entry;    // the result stays alive while later prefetches touch the cache
+            const StepResult &R = *S.current;
+            const size_t ng = R.groups.size() / 4;
+            const int64_t here_t = tid, here_s = s, here_e = e;      // `here` is not modified before all groups are done
+            struct Ref { int64_t t, l, r; bool l_bool; std::vector<int64_t> bps; };
+            std::vector<Ref> refined;
+            int64_t cand_at = 0;
+            for (size_t gi = 0; gi < ng; ++gi) {
+                const int64_t c = R.groups[4 * gi], b0 = R.groups[4 * gi + 1], b1 = R.groups[4 * gi + 2], n_c = R.groups[4 * gi + 3];
+                const int64_t *cand = R.cand.data() + 13 * cand_at;
+                cand_at += n_c;
+                if (c < 0 || c >= S.n_tid || b0 < 0 || b1 < 0 || b0 >= nseg(c) || b1 >= nseg(c)) return BFS_ERR_INDEX;
+                const int64_t ns = sstart(c, b0), ne = send(c, b1);
+                event(1, n_c);
+                const Calls &calls = R.calls[gi];
+                if (P.log_debug) for (int32_t q = 0; q < calls.n_clusters; ++q) event(2, calls.cluster_size[(size_t)q]);
+                std::vector<int64_t> found;
+                for (int32_t q = 0; q < calls.n_calls; ++q) {
+                    const int64_t head = calls.head[(size_t)q];
+                    const int64_t *h = cand + 13 * head;
+                    const int64_t f[11] = {h[0], calls.p1[(size_t)q], h[2], h[3], calls.p2[(size_t)q], h[5], h[6], h[7], h[8], h[9], h[10]};
+                    const int64_t c0 = (int64_t)O.chunk_read.size();
+                    for (int64_t u = calls.sup_off[(size_t)q]; u < calls.sup_off[(size_t)q + 1]; ++u) {
+                        const int64_t *m = cand + 13 * calls.sup_idx[(size_t)u];
+                        O.chunk_read.push_back(m[6]);
+                        O.chunk_i.push_back(m[7]);
+                        O.chunk_j.push_back(m[8]);
+                    }
+                    const int64_t k = addbp(f, calls.stats.data() + 6 * (size_t)q, calls.flags[(size_t)q], ccid, {c0, (int64_t)O.chunk_read.size()});
+                    if (std::find(found.begin(), found.end(), k) == found.end()) found.push_back(k);
+                }
+                struct In { int64_t cni, pos, k; };
+                struct Out { int64_t t, cni, pos, k; };
+                std::vector<In> inside;
+                std::vector<Out> outside;
+                for (int64_t k : found) {
+                    const int64_t *bp = O.bps[(size_t)k].f;
+                    const int64_t t1 = bp[0], p1 = bp[1], t2 = bp[3], p2 = bp[4];
+                    // (an IndexError / KeyError of pos2cni(..)[0] ends this breakpoint's turn — what was appended before stays)
+                    if (overlap(t1, p1, p1, here_t, here_s, here_e) && overlap(t2, p2, p2, c, ns, ne)) {
+                        const int64_t q = pos2cni(t2, p2);
+                        if (q >= 0) inside.push_back({q, p2, k});
+                    } else if (overlap(t2, p2, p2, here_t, here_s, here_e) && overlap(t1, p1, p1, c, ns, ne)) {
+                        const int64_t q = pos2cni(t1, p1);
+                        if (q >= 0) inside.push_back({q, p1, k});
+                    } else {
+                        event(3);
+                        const bool o1 = overlap(t1, p1, p1, c, ns, ne), o2 = overlap(t2, p2, p2, c, ns, ne);
+                        const int64_t q1 = pos2cni(t1, p1);
+                        if (q1 < 0) continue;
+                        if (o1) inside.push_back({q1, p1, k}); else outside.push_back({t1, q1, p1, k});
+                        const int64_t q2 = pos2cni(t2, p2);
+                        if (q2 < 0) continue;
+                        if (o2) inside.push_back({q2, p2, k}); else outside.push_back({t2, q2, p2, k});
+                    }
+                }
+                if (found.empty()) continue;
+                std::stable_sort(inside.begin(), inside.end(), [](const In &a, const In &b) { return a.cni != b.cni ? a.cni < b.cni : a.pos < b.pos; });
+                for (const Out &o : outside)
+                    if (o.t < 0 || o.t >= S.n_tid || P.chr_rank[o.t] < 0) { O.err_tid = o.t; return BFS_ERR_KEY_CHRIDX; }
+                std::stable_sort(outside.begin(), outside.end(), [&](const Out &a, const Out &b) {
+                    const int32_t ra = P.chr_rank[a.t], rb = P.chr_rank[b.t];
+                    if (ra != rb) return ra < rb;
+                    if (a.cni != b.cni) return a.cni < b.cni;
+                    return a.pos < b.pos;
+                });
+                const int64_t n_c_seg = nseg(c);
+                auto seg_ok = [&](int64_t t, int64_t k) { return k >= 0 && k < nseg(t); };
+                for (const In &x : inside) if (!seg_ok(c, x.cni)) return BFS_ERR_INDEX;
+                for (const Out &x : outside) if (!seg_ok(x.t, x.cni)) return BFS_ERR_INDEX;
+                if (n_c_seg == 0) return BFS_ERR_INDEX;
+                // ---- runs of `inside` breakpoints -> refined intervals on contig c (ibg:484-546)
+                auto split_inside = [&](size_t k) {
+                    const int64_t nil = sstart(c, inside[k + 1].cni), lir = send(c, inside[k].cni);
+                    const double ncn = scn(c, inside[k + 1].cni), lcn = scn(c, inside[k].cni);
+                    const bool amp = ncn >= gain || lcn >= gain;
+                    const int64_t dpos = inside[k + 1].pos - inside[k].pos;
+                    return inside[k + 1].cni - inside[k].cni > 2 || (double)(nil - lir) > (double)S.max_seq_len / 2.0 || dpos > S.max_seq_len ||
+                           (!amp && nil - lir > 2 * D) || (!amp && dpos > 3 * D);
+                };
+                size_t first = 0;
+                for (size_t k = 0; k + 1 < inside.size(); ++k) {
+                    if (!split_inside(k)) continue;
+                    const In &f = inside[first], &z = inside[k];
+                    const int64_t lir = send(c, z.cni);
+                    int64_t l = std::max((!(scn(c, f.cni) >= gain) ? f.pos : sstart(c, f.cni)) - D, sstart(c, 0));
+                    int64_t r = std::min((!(scn(c, z.cni) >= gain) ? z.pos : lir) + D, send(c, n_c_seg - 1));
+                    const double fcn = scn(c, f.cni);
+                    if ((fcn != 0.0) && f.pos - half > l) l = f.pos - half;                 // Q3: the CN value as a truth value (NaN is true)
+                    if (z.pos + half < r) r = z.pos + half;
+                    if (!pos2cni_any(c, l)) l = sstart(c, f.cni);
+                    if (!pos2cni_any(c, r)) r = lir;
+                    Ref ref{c, l, r, false, {}};
+                    for (size_t j = first; j <= k; ++j) ref.bps.push_back(inside[j].k);
+                    refined.push_back(std::move(ref));
+                    first = k + 1;
+                }
+                if (!inside.empty()) {
+                    const In &f = inside[first], &z = inside.back();
+                    int64_t l = std::max((!(scn(c, f.cni) >= gain) ? f.pos : sstart(c, f.cni)) - D, sstart(c, 0));
+                    int64_t r = std::min((!(scn(c, z.cni) >= gain) ? z.pos : send(c, z.cni)) + D, send(c, n_c_seg - 1));
+                    bool l_bool = false;
+                    if (f.pos - half > l) { l = (f.pos - half > l) ? 1 : 0; l_bool = true; }          // Q2: the comparison result is stored
+                    if (z.pos + half < r) r = z.pos + half;
+                    if (!pos2cni_any(c, l)) { l = sstart(c, f.cni); l_bool = false; }
+                    if (!pos2cni_any(c, r)) r = send(c, z.cni);
+                    Ref ref{c, l, r, l_bool, {}};
+                    for (size_t j = first; j < inside.size(); ++j) ref.bps.push_back(inside[j].k);
+                    refined.push_back(std::move(ref));
+                }
+                // ---- runs of `outside` ends -> refined intervals on their own contigs (ibg:548-612)
+                auto split_outside = [&](size_t k) {
+                    const Out &a = outside[k], &b = outside[k + 1];
+                    const int64_t nil = sstart(b.t, b.cni), lir = send(a.t, a.cni);
+                    const double ncn = scn(b.t, b.cni), lcn = scn(a.t, a.cni);
+                    const bool amp = ncn >= gain || lcn >= gain;
+                    return b.t != a.t || b.cni - a.cni > 2 || (double)(nil - lir) > (double)S.max_seq_len / 2.0 || b.pos - a.pos > S.max_seq_len ||
+                           (!amp && nil - lir > 2 * D) || (!amp && b.pos - a.pos > 3 * D);
+                };
+                first = 0;
+                for (size_t k = 0; k + 1 < outside.size(); ++k) {
+                    if (!split_outside(k)) continue;
+                    const Out &f = outside[first], &z = outside[k];
+                    const int64_t lir = send(z.t, z.cni);
+                    int64_t l = std::max((!(scn(f.t, f.cni) >= gain) ? f.pos : sstart(f.t, f.cni)) - D, sstart(f.t, 0));
+                    int64_t r = std::min((!(scn(z.t, z.cni) >= gain) ? z.pos : lir) + D, send(z.t, nseg(z.t) - 1));
+                    if (f.pos - half > l) l = f.pos - half;
+                    if (z.pos + half < r) r = z.pos + half;
+                    if (!pos2cni_any(f.t, l)) l = sstart(f.t, f.cni);
+                    if (!pos2cni_any(z.t, r)) r = lir;
+                    refined.push_back(Ref{f.t, l, r, false, {}});
+                    first = k + 1;
+                }
+                if (!outside.empty()) {
+                    const Out &f = outside[first], &z = outside.back();
+                    int64_t l = std::max((!(scn(f.t, f.cni) >= gain) ? f.pos : sstart(f.t, f.cni)) - D, sstart(f.t, 0));
+                    int64_t r = std::min((!(scn(z.t, z.cni) >= gain) ? z.pos : send(z.t, z.cni)) + D, send(z.t, nseg(z.t) - 1));
+                    if (f.pos - half > l) l = f.pos - half;
+                    if (z.pos + half < r) r = z.pos + half;
+                    if (!pos2cni_any(f.t, l)) l = sstart(f.t, f.cni);
+                    if (!pos2cni_any(f.t, r)) {
+                        if (!seg_ok(f.t, z.cni)) return BFS_ERR_INDEX;
+                        r = send(f.t, z.cni);                                            // (by[f[0]][z[1]]: the FIRST end's contig, as written)
+                    }
+                    refined.push_back(Ref{f.t, l, r, false, {}});
+                }
+            }
+            // ---- the refined intervals against the interval list (ibg:614-673)
+            for (const Ref &ref : refined) {
+                // interval_exclusive (bu:54-67): parts of the candidate not covered by the list + the (CPython) set of intervals it overlaps
+                PySetEmu hit;
+                struct Part { int64_t s, e; };
+                std::vector<Part> parts{{ref.l, ref.r}};
+                const int64_t n_iv = (int64_t)(O.iv.size() / 5);
+                for (int64_t k = 0; k < n_iv; ++k) {
+                    const int64_t bt = O.iv[5 * k], bs = O.iv[5 * k + 1], be = O.iv[5 * k + 2];
+                    for (int64_t j = (int64_t)parts.size() - 1; j >= 0; --j) {
+                        const Part p = parts[(size_t)j];
+                        if (overlap(ref.t, p.s, p.e, bt, bs, be)) {
+                            hit.add((int32_t)k, (int64_t)k);
+                            parts.erase(parts.begin() + j);
+                            if (p.s < bs) parts.push_back({p.s, bs - 1});
+                            if (p.e > be) parts.push_back({be + 1, p.e});
+                        }
+                    }
+                }
+                std::vector<int64_t> hits;
+                for (size_t slot = 0; slot <= hit.mask; ++slot)
+                    if (hit.key[slot] >= 0) hits.push_back(hit.key[slot]);
+                auto bp_touches = [&](const int64_t *bp, int64_t o, bool first_end) {
+                    const int64_t t = first_end ? bp[0] : bp[3], p = first_end ? bp[1] : bp[4];
+                    return overlap(t, p, p, O.iv[5 * o], O.iv[5 * o + 1], O.iv[5 * o + 2]);
+                };
+                if (parts.empty()) {
+                    for (int64_t k : ref.bps) {
+                        const int64_t *bp = O.bps[(size_t)k].f;
+                        for (int64_t o : hits)
+                            if ((o != cur && bp_touches(bp, o, true)) || bp_touches(bp, o, false)) conn_add(cur, o, k);        // Q5
+                    }
+                    for (int64_t o : hits)
+                        if (o != cur && O.iv[5 * o + 3] < 0) {
+                            queue.push_back(o);
+                            const int rc2 = enqueue(o);
+                            if (rc2 != CORAL_OK) return rc2;
+                        }
+                } else {
+                    for (const Part &part : parts) {
+                        const int64_t nai = (int64_t)(O.iv.size() / 5);
+                        // (a part that still starts at the candidate's own `l` keeps its bool-ness, Q2)
+                        const int64_t row[5] = {ref.t, part.s, part.e, -1, (ref.l_bool && part.s == ref.l) ? 1 : 0};
+                        O.iv.insert(O.iv.end(), row, row + 5);
+                        event(4, ref.t, part.s, part.e, row[4]);
+                        const int64_t ck = conn_index(cur, nai, true);
+                        O.conn_val[(size_t)ck].clear();                                  // conn[(cur, nai)] = set()
+                        for (int64_t k : ref.bps) {
+                            if (hits.empty()) {
+                                O.conn_val[(size_t)conn_index(cur, nai, false)].push_back(k);
+                                continue;
+                            }
+                            const int64_t *bp = O.bps[(size_t)k].f;
+                            for (int64_t o : hits) {
+                                if (bp_touches(bp, o, true) || bp_touches(bp, o, false)) conn_add(cur, o, k);
+                                else O.conn_val[(size_t)conn_index(cur, nai, false)].push_back(k);
+                            }
+                        }
+                        queue.push_back(nai);
+                        const int rc2 = enqueue(nai);
+                        if (rc2 != CORAL_OK) return rc2;
+                    }
+                }
+            }
+        }
+        return CORAL_OK;
+    }
+};
 }  // namespace
 
 extern "C" void *coral_search_create(int64_t n_reads, int64_t n_rows, const int64_t *off, const int64_t *row_read,
@@ -651,4 +998,80 @@ extern "C" int coral_search_between(void *h, int64_t n_sel, const int32_t *reads
     R.flatten();
     if (!contigs_ok) { snprintf(S.err, sizeof(S.err), "search_between: contig outside chr1..22,X,Y,M"); return CORAL_ERR_FORMAT; }
     return CORAL_OK;
+}
+
+// The interval search of one build in ONE call: ibg's find_amplicon_intervals loop over the seed intervals + find_interval_i.
+// iv: int64 [n_seed][4] = contig id, start, end, ccid (-1) of the seed intervals after the CN-segment snap (ibg:343-360).
+extern "C" int coral_search_bfs(void *h, int32_t n_seed, const int64_t *iv, const double *seg_cn, const int64_t *seg_ix,
+                                const int32_t *chr_rank, const uint8_t *tid_has_rows, double cn_gain, int64_t interval_delta,
+                                int32_t log_level) {
+    if (!h || n_seed < 0 || (n_seed > 0 && !iv) || !seg_cn || !seg_ix || !chr_rank || !tid_has_rows) return CORAL_ERR_ARG;
+    Search &S = *(Search *)h;
+    S.bfs = std::make_shared<BfsOut>();
+    BfsOut &O = *S.bfs;
+    for (int32_t k = 0; k < n_seed; ++k) {
+        if (iv[4 * k] < 0 || iv[4 * k] >= S.n_tid) { snprintf(S.err, sizeof(S.err), "search_bfs: contig id out of range"); return CORAL_ERR_ARG; }
+        const int64_t row[5] = {iv[4 * k], iv[4 * k + 1], iv[4 * k + 2], iv[4 * k + 3], 0};
+        O.iv.insert(O.iv.end(), row, row + 5);
+    }
+    const BfsParams P{seg_cn, seg_ix, chr_rank, tid_has_rows, cn_gain, interval_delta, log_level >= 1, log_level >= 2};
+    BfsRun run(S, P, O);
+    int rc = CORAL_OK;
+    if (S.n_reads > 0)
+        for (int32_t ai = 0; ai < n_seed && rc == CORAL_OK; ++ai) rc = run.enqueue(ai);
+    int64_t ccid = 0;
+    for (int32_t ai = 0; ai < n_seed && rc == CORAL_OK; ++ai)
+        if (O.iv[5 * (size_t)ai + 3] == -1) {
+            rc = run.bfs_from(ai, ccid);
+            ++ccid;
+        }
+    if (rc == BFS_ERR_KEY_CHROM) snprintf(S.err, sizeof(S.err), "search_bfs: KeyError contig %lld has no hashed alignments", (long long)O.err_tid);
+    else if (rc == BFS_ERR_KEY_CHRIDX) snprintf(S.err, sizeof(S.err), "search_bfs: KeyError contig %lld outside chr1..22,X,Y,M", (long long)O.err_tid);
+    else if (rc == BFS_ERR_INDEX) snprintf(S.err, sizeof(S.err), "search_bfs: segment index out of range");
+    // ---- flatten
+    O.bp_flat.clear(); O.bp_meta.clear(); O.bp_stats.clear(); O.chunk_off.clear();
+    for (const BfsBp &b : O.bps) {
+        O.bp_flat.insert(O.bp_flat.end(), b.f, b.f + 11);
+        const int64_t m[4] = {b.flags, b.ccid, (int64_t)(O.chunk_off.size() / 2), (int64_t)(O.chunk_off.size() / 2 + b.chunks.size())};
+        O.bp_meta.insert(O.bp_meta.end(), m, m + 4);
+        O.bp_stats.insert(O.bp_stats.end(), b.stats, b.stats + 6);
+        for (const auto &c : b.chunks) { O.chunk_off.push_back(c[0]); O.chunk_off.push_back(c[1]); }
+    }
+    O.conn_flat.clear(); O.conn_off.assign(1, 0); O.conn_vals.clear();
+    for (size_t k = 0; k < O.conn_key.size(); ++k) {
+        O.conn_flat.push_back(O.conn_key[k][0]);
+        O.conn_flat.push_back(O.conn_key[k][1]);
+        O.conn_vals.insert(O.conn_vals.end(), O.conn_val[k].begin(), O.conn_val[k].end());
+        O.conn_off.push_back((int64_t)O.conn_vals.size());
+    }
+    return rc;
+}
+
+// Arrays of the last coral_search_bfs (owned by the handle until the next one / coral_search_free); which =
+//   0 intervals int64[n][5] (contig, start, end, ccid, start-is-a-bool)   1 breakpoints int64[n][11] (c1 p1 o1 c2 p2 o2 head name id, i, j, gap, swapped)
+//   2 per breakpoint int64[n][4] (flags, ccid, first chunk, end chunk)    3 statistics double[n][6]
+//   4 chunks int64[n][2] (begin, end into 5 / 6 / 7)    5 / 6 / 7 support triples: read name id, i, j
+//   8 connection keys int64[n][2], insertion order    9 offsets int64[n + 1] into 10    10 breakpoint indices added per key, in order
+//   11 events int64[n][6] (for the log)
+extern "C" int coral_search_bfs_get(void *h, int32_t which, const void **ptr, int64_t *n) {
+    if (!h || !ptr || !n) return CORAL_ERR_ARG;
+    Search &S = *(Search *)h;
+    if (!S.bfs) return CORAL_ERR_ARG;
+    BfsOut &O = *S.bfs;
+    auto give = [&](const auto &v) { *ptr = v.data(); *n = (int64_t)v.size(); return CORAL_OK; };
+    switch (which) {
+        case 0: return give(O.iv);
+        case 1: return give(O.bp_flat);
+        case 2: return give(O.bp_meta);
+        case 3: return give(O.bp_stats);
+        case 4: return give(O.chunk_off);
+        case 5: return give(O.chunk_read);
+        case 6: return give(O.chunk_i);
+        case 7: return give(O.chunk_j);
+        case 8: return give(O.conn_flat);
+        case 9: return give(O.conn_off);
+        case 10: return give(O.conn_vals);
+        case 11: return give(O.events);
+        default: return CORAL_ERR_ARG;
+    }
 }

@@ -510,15 +510,79 @@ class bam_to_breakpoint_nanopore():
                 iv[2] = by[c][rcni][2] + self.interval_delta
         ccid = 0
         _lib.check_pyset_replay()            # once per process: the set replay must match this interpreter's sets
-        if len(self._chim.read):
+        if not _VERIFY_SET_ORDER and os.environ.get("CORAL_SEARCH_BFS", "native") != "python" and not self.new_bp_list and \
+                not self.amplicon_interval_connections:
+            self._find_intervals_native()
+        else:                                # the same search step by step from Python (tests: every set union re-checked)
+            if len(self._chim.read):
+                for ai in range(len(self.amplicon_intervals)):
+                    self._prefetch_step(ai)
             for ai in range(len(self.amplicon_intervals)):
-                self._prefetch_step(ai)
-        for ai in range(len(self.amplicon_intervals)):
-            if self.amplicon_intervals[ai][3] == -1:
-                self.find_interval_i(ai, ccid)
-                ccid += 1
+                if self.amplicon_intervals[ai][3] == -1:
+                    self.find_interval_i(ai, ccid)
+                    ccid += 1
         logging.debug(_t() + "Identified %d amplicon intervals in total." % len(self.amplicon_intervals))
         self._merge_intervals()
+
+    def _find_intervals_native(self):
+        """The loop over the seeds + find_interval_i (ibg:343-673) as ONE native call (coral_search_bfs): the pure steps run
+        ahead on worker threads as before, and the order-dependent half (addbp, interval refinement, interval_exclusive,
+        connections) runs next to them instead of one Python round trip per interval.  What comes back is turned into the
+        reference's containers here: interval lists, new_bp_list rows with lazy support sets, the connections dict in its
+        insertion order, and the log lines in the order the reference emits them."""
+        chroms = self.rec.header_chroms
+        by = self.cns_intervals_by_chr
+        S = self._search()
+        n_tid = len(chroms)
+        seg_cn = np.fromiter((float(v[3]) for c in chroms for v in by.get(c, ())), dtype=np.float64)
+        seg_ix = np.concatenate([np.asarray(self.cns_tree[c][2], dtype=np.int64) if c in self.cns_tree else np.zeros(0, dtype=np.int64)
+                                 for c in chroms]) if n_tid else np.zeros(0, dtype=np.int64)
+        assert len(seg_ix) == len(seg_cn)
+        has = np.zeros(max(n_tid, 1), dtype=np.uint8)
+        has[list(self._seg_tids)] = 1
+        seeds = [[self._tid_of[iv[0]], int(iv[1]), int(iv[2]), int(iv[3])] for iv in self.amplicon_intervals]
+        log = logging.getLogger()
+        level = 2 if log.isEnabledFor(logging.DEBUG) else 1 if log.isEnabledFor(logging.WARNING) else 0
+        R = S.bfs(seeds, seg_cn, seg_ix, self.rec.chr_rank, has, self.cn_gain, self.interval_delta, level)
+        iv = R[0].reshape(-1, 5).tolist()
+        self.amplicon_intervals = [[chroms[t], bool(s) if isb else s, e, cc] for t, s, e, cc, isb in iv]
+        names = self.rec.names
+        bp, meta, stats = R[1].reshape(-1, 11), R[2].reshape(-1, 4).tolist(), R[3].reshape(-1, 6)
+        chunks, c_read, c_i, c_j = R[4].reshape(-1, 2).tolist(), R[5], R[6], R[7]
+        head_names = names.take(bp[:, 6]) if len(bp) else []
+        for k, f in enumerate(bp.tolist()):
+            flags, cc, ch0, ch1 = meta[k]
+            a, b = chunks[ch0]
+            support = ReadSupportSet(names, c_read[a:b], c_i[a:b], c_j[a:b])
+            for a, b in chunks[ch0 + 1:ch1]:
+                support |= ReadSupportSet(names, c_read[a:b], c_i[a:b], c_j[a:b])
+            st = stats[k].tolist()
+            if flags & 1:
+                st[2] = 0                                 # the reference's ValueError branch stores the integer 0
+            if flags & 2:
+                st[3] = 0
+            self.new_bp_list.append([chroms[f[0]], f[1], _ORI[f[2]], chroms[f[3]], f[4], _ORI[f[5]], (head_names[k], f[7], f[8]),
+                                     f[9], f[10], support])
+            self.new_bp_ccids.append(cc)
+            self.new_bp_stats.append(st)
+        conn = self.amplicon_interval_connections
+        keys, off, vals = R[8].reshape(-1, 2).tolist(), R[9].tolist(), R[10].tolist()
+        for q, (a, b) in enumerate(keys):
+            s_ = conn[(a, b)] = set()
+            for v in vals[off[q]:off[q + 1]]:
+                s_.add(v)
+        if level:
+            for ty, a, b, c, d, e in R[11].reshape(-1, 6).tolist():
+                if ty == 3:
+                    logging.warning(_t() + "\t\tExact breakpoint outside amplicon interval.")
+                elif ty == 0:
+                    logging.debug(_t() + "\t\tNext amplicon interval %d: %s." % (a, [chroms[b], c, d, e]))
+                elif ty == 1:
+                    logging.debug(_t() + "\t\tFound %d reads connecting the two intervals." % a)
+                elif ty == 2:
+                    logging.debug(_t() + "New cluster of size %d." % a)
+                elif ty == 4:
+                    logging.debug(_t() + "\t\tAdded new interval %s to the amplicon interval list." % [chroms[a], bool(b) if d else b, c, -1])
 
     def _merge_intervals(self):
         """Sort, merge adjacent / overlapping intervals, remap connections, relabel components (ibg:236-319)."""

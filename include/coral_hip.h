@@ -215,6 +215,26 @@ int coral_search_between(void *handle, int64_t n_sel, const int32_t *reads, int6
 int coral_search_result(void *handle, int64_t *n_meta, const int64_t **meta, int64_t *n_cand, const int64_t **cand,
                         int64_t *n_sup, const int64_t **sup, const double **stats, const int64_t **order_off,
                         const int32_t **order);
+/* coral_search_bfs — the WHOLE interval search of a build in one call: the loop over the seed intervals and the breadth-first
+ * search of find_interval_i (/root/reference/src/infer_breakpoint_graph.py:343-673) incl. its order-dependent half: addbp
+ * (ibg:326-340), the refinement of the reached segments into new intervals (ibg:459-612), interval_exclusive (bu:54-67) and
+ * the connection bookkeeping (ibg:614-673); the pure steps run ahead on the handle's worker threads as with
+ * coral_search_prefetch / _step.  iv int64[n_seed][4] = contig id, start, end, ccid (-1) of the seeds after the CN-segment snap;
+ * seg_cn / seg_ix = CN value and the reference's per-chromosome index of every CN segment (layout of seg_start / seg_end);
+ * chr_rank[contig] = rank in chr1..22,X,Y,M or -1; tid_has_rows[contig] = 1 if some alignment is hashed to the contig's
+ * segments; log_level 0 none, 1 warnings, 2 + debug events.  Errors: CORAL_ERR_FORMAT / -10 / -11 = the reference's KeyError
+ * cases, -12 = its IndexError (coral_search_error has the text).  coral_search_bfs_get(which) returns the result arrays:
+ *   0 intervals int64[n][5] (contig, start, end, ccid, start-is-a-bool — Appendix A Q2)
+ *   1 breakpoints int64[n][11] (c1 p1 o1 c2 p2 o2, read name id / i / j of the head candidate, query gap, swapped)
+ *   2 int64[n][4] (flags of coral_call_breakpoints, ccid, first and end chunk)   3 statistics double[n][6]
+ *   4 chunks int64[n][2] (begin, end into 5 / 6 / 7)   5 / 6 / 7 support triples (read name id, i, j) — chunk 0 of a breakpoint
+ *     is the set it was created with, every later chunk arrived through `|=` (ibg:330)
+ *   8 connection keys int64[n][2] in insertion order   9 offsets int64[n + 1] into 10   10 breakpoint indices in order of addition
+ *   11 events int64[n][6] for the log (type, arguments). */
+int coral_search_bfs(void *handle, int32_t n_seed, const int64_t *iv, const double *seg_cn, const int64_t *seg_ix,
+                     const int32_t *chr_rank, const uint8_t *tid_has_rows, double cn_gain, int64_t interval_delta,
+                     int32_t log_level);
+int coral_search_bfs_get(void *handle, int32_t which, const void **ptr, int64_t *n);
 
 /* ------------------------------------------------------------------------------------------------
  * coral_read_counter — copy a device counter to the host (synchronises `stream`).

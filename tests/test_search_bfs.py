@@ -1,0 +1,101 @@
+"""The interval search as ONE native call (coral_search_bfs) against the step-by-step Python search it replaces (which the
+reference's goldens pin, tests/test_host_logic.py): same intervals, breakpoints, support sets, statistics, component ids and
+connections — dict and list ORDER included — on the golden data sets and under parameter settings chosen to drive the search
+through its other branches (short max_seq_len: many runs and `outside` ends; small interval_delta; cn_gain above / below every
+segment; low cluster cut-offs)."""
+import itertools
+import json
+import os
+
+import pytest
+
+from tests.canon import canon
+from tests.product_check import install_cpu_kernel_fakes, load_case
+
+
+def _prepared(case, golden_dir, tmp_path):
+    from coral_amd import infer_breakpoint_graph as ibg, synth
+    from coral_amd.records import DeviceRecords
+    gold, cfg, rec = load_case(golden_dir, case)
+    cn, seeds = str(tmp_path / "cn.bed"), str(tmp_path / "seeds.bed")
+    synth.write_cn_bed(cfg, cn)
+    synth.write_seed_bed(cfg, seeds)
+    b = ibg.bam_to_breakpoint_nanopore(None, seeds, records=DeviceRecords(rec, "cpu"))
+    b.read_cns(cn)
+    b.fetch()
+    b.hash_alignment_to_seg()
+    return b
+
+
+def _search(b, mode, params, seed_intervals):
+    """find_amplicon_intervals on a fresh search state of ``b`` (mode: 'python' = step by step, 'native' = coral_search_bfs)."""
+    import copy
+    os.environ["CORAL_SEARCH_BFS"] = mode
+    try:
+        b.amplicon_intervals = copy.deepcopy(seed_intervals)
+        b.new_bp_list, b.new_bp_stats, b.new_bp_ccids = [], [], []
+        b.amplicon_interval_connections = {}
+        if b._search_ctx is not None:
+            b._search_ctx.close()
+        b._search_ctx = None
+        for k, v in params.items():
+            setattr(b, k, v)
+        events = []
+        import logging
+
+        class H(logging.Handler):
+            def emit(self, r):
+                events.append((r.levelname, r.getMessage().split("\t", 1)[1] if "\t" in r.getMessage() else r.getMessage()))
+        h = H()
+        root = logging.getLogger()
+        old = root.level
+        root.addHandler(h)
+        root.setLevel(logging.DEBUG)
+        try:
+            b.find_amplicon_intervals()
+        finally:
+            root.removeHandler(h)
+            root.setLevel(old)
+        snap = dict(intervals=canon(b.amplicon_intervals), bps=canon(b.new_bp_list), stats=canon(b.new_bp_stats), ccids=canon(b.new_bp_ccids),
+                    conn=canon(b.amplicon_interval_connections))
+        # log lines of the search itself (same text, same order; the time stamps differ)
+        snap["log"] = [e for e in events if any(t in e[1] for t in ("Next amplicon interval", "reads connecting", "New cluster", "Exact breakpoint",
+                                                                     "Added new interval"))]
+        return snap
+    finally:
+        os.environ.pop("CORAL_SEARCH_BFS", None)
+
+
+DEFAULTS = dict(max_seq_len=2000000, cn_gain=5.0, interval_delta=100000, max_breakpoint_distance_cutoff=2000, min_bp_match_cutoff_=100)
+GRID = [dict(), dict(max_seq_len=200000), dict(max_seq_len=40000, interval_delta=5000), dict(interval_delta=1000), dict(interval_delta=700000),
+        dict(cn_gain=0.5), dict(cn_gain=1e9), dict(cn_gain=1e9, max_seq_len=150000, interval_delta=20000), dict(max_breakpoint_distance_cutoff=50),
+        dict(max_breakpoint_distance_cutoff=300000), dict(min_cluster_cutoff=1), dict(min_cluster_cutoff=1, max_seq_len=30000, interval_delta=300, cn_gain=0.5),
+        dict(min_cluster_cutoff=2, max_seq_len=600000, interval_delta=250000)]
+
+
+@pytest.mark.parametrize("case", ["tiny_edge", "small", "ultra", "cfg3_2amp"])
+def test_native_bfs_equals_stepwise_search(case, golden_dir, tmp_path, monkeypatch):
+    import copy
+    install_cpu_kernel_fakes(monkeypatch)
+    b = _prepared(case, golden_dir, tmp_path)
+    seeds = copy.deepcopy(b.amplicon_intervals)
+    cutoff0 = b.min_cluster_cutoff
+    n_bps, n_out, n_added = 0, 0, 0
+    for extra in GRID:
+        params = dict(DEFAULTS, min_cluster_cutoff=cutoff0)
+        params.update(extra)
+        try:
+            want = _search(b, "python", params, seeds)
+        except Exception as exc:          # noqa: BLE001 — the reference's own KeyError / IndexError cases: same exception from the native search
+            with pytest.raises(type(exc)):
+                _search(b, "native", params, seeds)
+            continue
+        got = _search(b, "native", params, seeds)
+        for k in want:
+            assert json.dumps(got[k]) == json.dumps(want[k]), (case, extra, k)
+        n_bps += len(want["bps"])
+        n_out += sum(1 for e in want["log"] if "Exact breakpoint" in e[1])
+        n_added += sum(1 for e in want["log"] if "Added new interval" in e[1])
+    assert n_bps > 0 and n_added > 0, "the grid never found a breakpoint / added an interval on this data set"
+    if case != "tiny_edge":
+        assert n_out > 0, "the grid never reached the `outside` branch on this data set"
