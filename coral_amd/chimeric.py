@@ -48,7 +48,11 @@ class ChimericTable:
         return len(self.qs)
 
 
-def build_chimeric_table(dr) -> ChimericTable:
+def _nothing_to_finish():
+    pass
+
+
+def build_chimeric_table(dr, defer_nm_stats: bool = False) -> ChimericTable:
     """ibg:139-174 + cp:232-269 for all reads: coral_sa_table (K3) does the SA-row work on the GPU; this wrapper adds the
     float NM rate (cp:268) and the NM statistics of the non-chimeric MAPQ-60 records (ibg:153-157)."""
     from . import kernels
@@ -56,12 +60,44 @@ def build_chimeric_table(dr) -> ChimericTable:
     from . import _lib
     T = ChimericTable()
     cnt, s0, s1 = C.c_int64(0), C.c_double(0.0), C.c_double(0.0)
-    rc = _lib.lib().coral_nm_stats(dr.n_total, dr.h_tid.ctypes.data, dr.h_sa_off.ctypes.data, dr.h_mapq.ctypes.data,
-                                   dr.h_nm.ctypes.data, dr.h_qlen.ctypes.data, C.byref(cnt), C.byref(s0), C.byref(s1))
-    if rc == -5:                                  # CORAL_ERR_ZERODIV: a counted record without SEQ (ibg:154)
-        raise ZeroDivisionError("division by zero")
-    _lib.check(rc, "coral_nm_stats")
-    T.n_mapq60_plain, T.nm_sum, T.nm_sum_sq = int(cnt.value), float(s0.value), float(s1.value)
+    box = {}
+
+    def nm_stats():
+        # one pass over all records, sums in the reference's order (a chain of dependent float adds: ~2 ms at 2 M records) — on a
+        # thread of its own (ctypes releases the GIL), next to the table kernels' round trips and read_cns
+        box["rc"] = _lib.lib().coral_nm_stats(dr.n_total, dr.h_tid.ctypes.data, dr.h_sa_off.ctypes.data, dr.h_mapq.ctypes.data,
+                                              dr.h_nm.ctypes.data, dr.h_qlen.ctypes.data, C.byref(cnt), C.byref(s0), C.byref(s1))
+
+    def finish():
+        T.finish_nm_stats = _nothing_to_finish          # (and the table no longer refers to this closure: no reference cycle)
+        th = box.pop("thread", None)
+        if th is not None:
+            th.join()
+            rc = box["rc"]
+            if rc == -5:                                  # CORAL_ERR_ZERODIV: a counted record without SEQ (ibg:154)
+                raise ZeroDivisionError("division by zero")
+            _lib.check(rc, "coral_nm_stats")
+            T.n_mapq60_plain, T.nm_sum, T.nm_sum_sq = int(cnt.value), float(s0.value), float(s1.value)
+    if dr.n_total >= 200000:
+        import threading
+        box["thread"] = threading.Thread(target=nm_stats, name="coral-nm-stats")
+        box["thread"].start()
+    else:
+        nm_stats()
+        box["thread"] = type("_Done", (), {"join": staticmethod(lambda: None)})()
+    T.finish_nm_stats = finish
+    try:
+        _fill_from_sa_table(T, dr)
+    except Exception:
+        finish()            # the reference meets a record it cannot divide by (ibg:154) before it parses any SA tag (cp:255): that error first
+        raise
+    if not defer_nm_stats:
+        finish()
+    return T
+
+
+def _fill_from_sa_table(T, dr):
+    from . import kernels
     cols, off, name_id, failed, rl, T.pairs, T.dev_rows, T.staging = kernels.sa_table(dr)
     T.read_length = rl
     T.name_id, T.failed, T.off = name_id, failed, off
@@ -71,7 +107,6 @@ def build_chimeric_table(dr) -> ChimericTable:
     T.nm = cols[7].astype(np.float64) / (T.qe - T.qs) if n_rows else np.zeros(0)
     T.cni0 = np.full(n_rows, -1, dtype=np.int64)
     T.cni1 = np.full(n_rows, -1, dtype=np.int64)
-    return T
 
 
 # ----------------------------------------------------------------------------------------------

@@ -240,12 +240,15 @@ PyObject *blob_hashes(PyObject *, PyObject *args) {
         return nullptr;
     }
     int64_t *out = static_cast<int64_t *>(ob.buf);
+    // ASCII names (all of them, in practice) are hashed from their bytes WITHOUT the interpreter lock: _Py_HashBytes touches no
+    // Python object, so this loop can run beside the build's main thread; the rare others are done afterwards through a str
+    Py_ssize_t bad = -1, n_other = 0;
+    Py_BEGIN_ALLOW_THREADS
     for (Py_ssize_t k = 0; k < ids.n; ++k) {
         const int64_t id = ids.p[k];
-        if (id < 0 || id >= B.n) {
-            PyBuffer_Release(&ob);
-            PyErr_SetString(PyExc_IndexError, "name id out of range");
-            return nullptr;
+        if (id < 0 || id >= B.n || B.o[id + 1] < B.o[id]) {
+            bad = k;
+            break;
         }
         const char *s = B.b + B.o[id];
         const Py_ssize_t len = (Py_ssize_t)(B.o[id + 1] - B.o[id]);
@@ -254,14 +257,31 @@ PyObject *blob_hashes(PyObject *, PyObject *args) {
         if (ascii) {
             out[k] = (int64_t)_Py_HashBytes(s, len);
         } else {
-            PyObject *u = B.str(id);
-            if (!u) {
-                PyBuffer_Release(&ob);
-                return nullptr;
-            }
-            out[k] = (int64_t)PyObject_Hash(u);
-            Py_DECREF(u);
+            out[k] = 0;
+            ++n_other;
         }
+    }
+    Py_END_ALLOW_THREADS
+    if (bad >= 0) {
+        PyBuffer_Release(&ob);
+        PyErr_SetString(PyExc_IndexError, "name id out of range");
+        return nullptr;
+    }
+    for (Py_ssize_t k = 0; n_other > 0 && k < ids.n; ++k) {
+        const int64_t id = ids.p[k];
+        const char *s = B.b + B.o[id];
+        const Py_ssize_t len = (Py_ssize_t)(B.o[id + 1] - B.o[id]);
+        bool ascii = true;
+        for (Py_ssize_t q = 0; q < len; ++q) ascii &= ((unsigned char)s[q] < 0x80);
+        if (ascii) continue;
+        PyObject *u = B.str(id);
+        if (!u) {
+            PyBuffer_Release(&ob);
+            return nullptr;
+        }
+        out[k] = (int64_t)PyObject_Hash(u);
+        Py_DECREF(u);
+        --n_other;
     }
     PyBuffer_Release(&ob);
     Py_RETURN_NONE;

@@ -148,6 +148,7 @@ struct Search {
     char err[256] = "";
     // CORAL_SEARCH_PROFILE=1: seconds per phase and work counters over all steps, printed when the handle is freed
     bool profile = false;
+    int64_t par_min_reads = 24000, par_min_cands = 6000;      // a step splits work of at least this size over helper threads (CORAL_SEARCH_PAR_MIN: tests)
     std::mutex pm;
     double t_reach = 0, t_union = 0, t_cand = 0, t_call = 0, t_wait = 0;
     long long n_steps = 0, n_visit = 0, n_adds = 0, n_keys = 0, n_union_items = 0, n_cand = 0, n_inline = 0;
@@ -344,9 +345,34 @@ void compute_step(Search &S, Scratch &T, const int64_t key[5], StepResult &R) {
             if (acc.key[slot_e] >= 0) R.order.push_back(acc.key[slot_e]);
         const int32_t *ord = R.order.data() + order_before;
         const size_t n_ord = R.order.size() - order_before;
-        for (size_t q = 0; q < n_ord; ++q) {
-            if (q + 6 < n_ord) __builtin_prefetch(S.pack.data() + S.pack_off[(size_t)ord[q + 6]]);
-            contigs_ok &= pairs_between(S, T, R.cand, ord[q], t1_, s1, e1, tid, s, e);
+        // alignment2bp of every read of the run, in the set's iteration order.  A big run is cut into consecutive chunks of reads
+        // that helper threads filter into lists of their own; the lists are appended in chunk order, so the result is the one
+        // a single pass gives (a step is on the search's critical path: the breadth-first search waits for it)
+        const int helpers = (int64_t)n_ord >= S.par_min_reads && n_ord >= 8 ? 3 : 0;
+        auto filter = [&](size_t q0, size_t q1, Scratch &sc, std::vector<int64_t> &dst) {
+            bool ok = true;
+            for (size_t q = q0; q < q1; ++q) {
+                if (q + 6 < q1) __builtin_prefetch(S.pack.data() + S.pack_off[(size_t)ord[q + 6]]);
+                ok &= pairs_between(S, sc, dst, ord[q], t1_, s1, e1, tid, s, e);
+            }
+            return ok;
+        };
+        if (helpers == 0) {
+            contigs_ok &= filter(0, n_ord, T, R.cand);
+        } else {
+            std::vector<std::vector<int64_t>> part((size_t)helpers);
+            std::vector<Scratch> scr((size_t)helpers);
+            std::vector<char> okv((size_t)helpers, 1);
+            std::vector<std::thread> th;
+            const size_t per = n_ord / (size_t)(helpers + 1);
+            for (int h = 0; h < helpers; ++h)
+                th.emplace_back([&, h]() { okv[(size_t)h] = filter(per * (size_t)(h + 1), h + 1 == helpers ? n_ord : per * (size_t)(h + 2), scr[(size_t)h], part[(size_t)h]); });
+            contigs_ok &= filter(0, per, T, R.cand);
+            for (int h = 0; h < helpers; ++h) {
+                th[(size_t)h].join();
+                contigs_ok &= okv[(size_t)h] != 0;
+                R.cand.insert(R.cand.end(), part[(size_t)h].begin(), part[(size_t)h].end());
+            }
         }
         R.order_off.push_back((int64_t)R.order.size());
         const int64_t n_c = (int64_t)((R.cand.size() - cand_before) / 13);
@@ -360,12 +386,21 @@ void compute_step(Search &S, Scratch &T, const int64_t key[5], StepResult &R) {
     if (!contigs_ok) return fail(CORAL_ERR_FORMAT, "search_step: contig outside chr1..22,X,Y,M");
     // ---- cluster_bp_list + the bpc2bp loop of every run (ibg:436-457: the sub-cluster counter never advances there, Q4)
     {
-        int64_t at = 0;
-        for (size_t g = 0; g < plan.size(); ++g) {
-            const int64_t n_c = R.groups[4 * g + 3];
-            run_calls(S, R.cand.data() + 13 * at, n_c, R.calls[g]);
-            at += n_c;
-        }
+        std::vector<int64_t> at(plan.size() + 1, 0);
+        for (size_t g = 0; g < plan.size(); ++g) at[g + 1] = at[g] + R.groups[4 * g + 3];
+        // runs are independent: the big ones on helper threads (largest first), the rest here
+        std::vector<size_t> big;
+        for (size_t g = 0; g < plan.size(); ++g)
+            if (R.groups[4 * g + 3] >= S.par_min_cands) big.push_back(g);
+        std::sort(big.begin(), big.end(), [&](size_t a, size_t b) { return R.groups[4 * a + 3] > R.groups[4 * b + 3]; });
+        if (big.size() > 4) big.resize(4);
+        if (big.size() < 2) big.clear();
+        std::vector<std::thread> th;
+        for (size_t k = 1; k < big.size(); ++k)
+            th.emplace_back([&, k]() { run_calls(S, R.cand.data() + 13 * at[big[k]], R.groups[4 * big[k] + 3], R.calls[big[k]]); });
+        for (size_t g = 0; g < plan.size(); ++g)
+            if (std::find(big.begin() + (big.empty() ? 0 : 1), big.end(), g) == big.end()) run_calls(S, R.cand.data() + 13 * at[g], R.groups[4 * g + 3], R.calls[g]);
+        for (auto &x : th) x.join();
     }
     R.flatten();
     if (S.profile) {
@@ -788,22 +823,39 @@ extern "C" void *coral_search_create(int64_t n_reads, int64_t n_rows, const int6
     S->off = off; S->row_read = row_read; S->read_hash = read_hash; S->read_name = read_name; S->e_key = e_key; S->e_row = e_row;
     S->pairs = pairs; S->n_tid = n_tid; S->seg_off = seg_off; S->seg_start = seg_start; S->seg_end = seg_end;
     S->pack_off.resize((size_t)n_reads);
-    S->pack.reserve((size_t)(2 * n_reads + 12 * n_rows));
-    for (int64_t r = 0; r < n_reads; ++r) {
-        const int64_t base = off[r], n = off[r + 1] - base;
-        if (n < 0 || base < 0 || base + n > n_rows) { delete S; return nullptr; }
-        S->pack_off[(size_t)r] = (int64_t)S->pack.size();
-        S->pack.push_back((int32_t)n);
-        S->pack.push_back((int32_t)base);
-        for (int64_t k = base; k < base + n; ++k) {
-            const int32_t *adj = pairs + 8 * (2 * k);
-            const int32_t w[12] = {(int32_t)row_tid[k], (int32_t)ra[k], (int32_t)rb[k], (int32_t)cni0[k], (int32_t)cni1[k],
-                                   pairs[8 * (2 * k + 1) + 5], adj[0], adj[1], adj[2], adj[3], adj[4], adj[5]};
-            S->pack.insert(S->pack.end(), w, w + 12);
+    {   // offsets first (2 + 12 ints per row), then the records are filled in parallel: 16 MB at 2 M reads, on the build's critical path
+        int64_t at = 0;
+        for (int64_t r = 0; r < n_reads; ++r) {
+            const int64_t base = off[r], n = off[r + 1] - base;
+            if (n < 0 || base < 0 || base + n > n_rows) { delete S; return nullptr; }
+            S->pack_off[(size_t)r] = at;
+            at += 2 + 12 * n;
         }
+        S->pack.resize((size_t)at);
+        auto fill = [&](int64_t r0, int64_t r1) {
+            for (int64_t r = r0; r < r1; ++r) {
+                const int64_t base = off[r], n = off[r + 1] - base;
+                int32_t *w = S->pack.data() + S->pack_off[(size_t)r];
+                *w++ = (int32_t)n;
+                *w++ = (int32_t)base;
+                for (int64_t k = base; k < base + n; ++k) {
+                    const int32_t *adj = pairs + 8 * (2 * k);
+                    const int32_t v[12] = {(int32_t)row_tid[k], (int32_t)ra[k], (int32_t)rb[k], (int32_t)cni0[k], (int32_t)cni1[k],
+                                           pairs[8 * (2 * k + 1) + 5], adj[0], adj[1], adj[2], adj[3], adj[4], adj[5]};
+                    memcpy(w, v, sizeof(v));
+                    w += 12;
+                }
+            }
+        };
+        const int nt = n_reads >= 40000 ? 4 : 1;
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(fill, n_reads * t / nt, n_reads * (t + 1) / nt);
+        fill(0, n_reads / nt);
+        for (auto &x : th) x.join();
     }
     const char *pe = getenv("CORAL_SEARCH_PROFILE");
     S->profile = pe && pe[0] == '1';
+    if (const char *pm = getenv("CORAL_SEARCH_PAR_MIN")) S->par_min_reads = S->par_min_cands = atoll(pm);
     S->main_result.clear();
     S->current = &S->main_result;
     return S;

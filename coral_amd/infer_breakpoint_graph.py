@@ -401,9 +401,21 @@ class bam_to_breakpoint_nanopore():
         self.scan()
         t1 = time.perf_counter()
         try:
-            self._chim_early = build_chimeric_table(self.rec)
+            self._chim_early = build_chimeric_table(self.rec, defer_nm_stats=True)
         except Exception as exc:                      # noqa: BLE001 — re-raised by fetch(), where the reference raises
             self._chim_early = exc
+        T = self._chim_early
+        if isinstance(T, ChimericTable) and len(T.name_id) >= 20000:
+            # hash(read name) of every chimeric read (the set-order replay of the interval search needs them): from the name
+            # bytes, on a thread of its own (no interpreter lock is held for it), beside read_cns / fetch / hash_alignment_to_seg
+            import threading
+            names, box = self.rec.names, {}
+
+            def hashes(ids=T.name_id):
+                box["h"] = names.hashes(ids)
+            th = threading.Thread(target=hashes, name="coral-name-hashes")
+            th.start()
+            T._hash_job = (th, box)
         if trace:
             sys.stderr.write("launch_record_kernels: scan issue %.1f ms, chimeric table %.1f ms\n" % ((t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3))
 
@@ -416,6 +428,7 @@ class bam_to_breakpoint_nanopore():
         if T is None:
             T = build_chimeric_table(self.rec)
         self._chim = T
+        T.finish_nm_stats()                           # (started with the table kernels; raises what the reference raises at ibg:154)
         if T.n_mapq60_plain == 0:
             raise ZeroDivisionError("float division by zero")                # ibg:159
         s0, s1 = T.nm_sum, T.nm_sum_sq                                        # sequential adds, as the reference
@@ -706,7 +719,13 @@ class bam_to_breakpoint_nanopore():
         construction at ibg:379-384, :412-418, without the 164 k str objects."""
         T = self._chim
         if getattr(T, "_hashes", None) is None:
-            T._hashes = self.rec.names.hashes(T.name_id)
+            job = getattr(T, "_hash_job", None)
+            if job is not None:                       # started with the record kernels
+                T._hash_job = None
+                job[0].join()
+                T._hashes = job[1].get("h")
+            if getattr(T, "_hashes", None) is None:
+                T._hashes = self.rec.names.hashes(T.name_id)
         return T._hashes
 
     def _search(self) -> PairSearch:

@@ -163,10 +163,15 @@ def segment_coverage(dr, scan: ScanResult, segs: Sequence[Tuple[int, int, int]],
     o = out.cpu().numpy()
     n_reads, n_bases = o[0].copy(), o[1].copy()
     if len(dr.h_nonacgt_rec):
-        nt = dr.h_tid[dr.h_nonacgt_rec]
-        npos = dr.h_nonacgt_pos
-        for j in range(S):
-            n_bases[j] -= int(((nt == sg[j, 0]) & (npos >= sg[j, 1]) & (npos < sg[j, 2])).sum())
+        # aligned non-ACGT bases inside each segment: two binary searches per segment in the (contig, position)-sorted list of
+        # those bases (sorted once per records object) instead of a pass over the list per segment
+        keys = getattr(dr, "_nonacgt_keys", None)
+        if keys is None:
+            keys = dr._nonacgt_keys = np.sort((dr.h_tid[dr.h_nonacgt_rec].astype(np.int64) << 32) | dr.h_nonacgt_pos.astype(np.int64))
+        clip = lambda v: np.clip(v, 0, (1 << 32) - 1)          # (positions are non-negative int32: clamping keeps the comparison)
+        lo = np.searchsorted(keys, (sg[:, 0] << 32) + clip(sg[:, 1]), side="left")
+        hi = np.searchsorted(keys, (sg[:, 0] << 32) + clip(sg[:, 2]), side="left")
+        n_bases -= np.maximum(hi - lo, 0)
     return n_reads, n_bases
 
 

@@ -93,6 +93,17 @@ def test_native_bfs_equals_stepwise_search(case, golden_dir, tmp_path, monkeypat
         got = _search(b, "native", params, seeds)
         for k in want:
             assert json.dumps(got[k]) == json.dumps(want[k]), (case, extra, k)
+        if extra in ({}, dict(max_seq_len=200000), dict(min_cluster_cutoff=1)):
+            # every step cut into helper-thread chunks (at full size the big steps are; here the threshold is forced down) and
+            # computed ahead on look-ahead threads: not a byte may change
+            os.environ["CORAL_SEARCH_PAR_MIN"], os.environ["CORAL_SEARCH_MIN_READS"], os.environ["CORAL_SEARCH_THREADS"] = "1", "0", "3"
+            try:
+                par = _search(b, "native", params, seeds)
+            finally:
+                for k in ("CORAL_SEARCH_PAR_MIN", "CORAL_SEARCH_MIN_READS", "CORAL_SEARCH_THREADS"):
+                    os.environ.pop(k, None)
+            for k in want:
+                assert json.dumps(par[k]) == json.dumps(want[k]), (case, extra, k, "helper threads")
         n_bps += len(want["bps"])
         n_out += sum(1 for e in want["log"] if "Exact breakpoint" in e[1])
         n_added += sum(1 for e in want["log"] if "Added new interval" in e[1])
