@@ -276,17 +276,26 @@ extern "C" int coral_nm_stats(int64_t n, const int32_t *tid, const int64_t *sa_o
 // (p, p + 1, p - 101, p + 101), intersects the four NAME sets and removes the names that support a discordant edge at either
 // node.  Here the four fetches arrive as record ordinals (coral_point_cover), names are ids, and a per-name stamp replaces
 // the sets: bit d of mark[name] = "covers position d of the current edge".
-extern "C" int coral_concordant_counts(int32_t n_edges, const int64_t *pt_off, const int64_t *pt_rec, const int32_t *rec_name,
-                                       int64_t n_rec, int64_t n_names, const int64_t *sup_off, const int64_t *sup_name,
-                                       int64_t *count) {
-    if (n_edges < 0 || n_names < 0 || !count || (n_edges > 0 && (!pt_off || !sup_off))) return CORAL_ERR_ARG;
+extern "C" int coral_concordant_counts(int32_t n_edges, const int64_t *pt_begin, const int64_t *pt_end, const int32_t *pt_rec,
+                                       int64_t n_pt_rec, const int32_t *rec_name, int64_t n_rec, int64_t n_names, const int64_t *sup_off,
+                                       const int64_t *sup_name, int64_t *count) {
+    if (n_edges < 0 || n_names < 0 || !count || (n_edges > 0 && (!pt_begin || !pt_end || !sup_off))) return CORAL_ERR_ARG;
     if (n_edges == 0) return CORAL_OK;
-    if ((pt_off[4 * (size_t)n_edges] > 0 && (!pt_rec || !rec_name)) || (sup_off[n_edges] > 0 && !sup_name)) return CORAL_ERR_ARG;
-    std::vector<uint32_t> mark((size_t)n_names, 0u);          // (edge + 1) << 6 | bits
+    for (int64_t p = 0; p < 4 * (int64_t)n_edges; ++p)
+        if (pt_begin[p] < 0 || pt_end[p] < pt_begin[p] || pt_end[p] > n_pt_rec) return CORAL_ERR_ARG;
+    if ((n_pt_rec > 0 && (!pt_rec || !rec_name)) || (sup_off[n_edges] > 0 && !sup_name)) return CORAL_ERR_ARG;
+    // one word per read name: epoch << 6 | bits.  The array lives on between calls (per thread) and the epoch keeps counting, so a
+    // build does not pay for clearing 8 MB at 2 M reads; it is cleared when it grows or when the epoch would wrap
+    static thread_local std::vector<uint32_t> mark;
+    static thread_local uint32_t epoch = 0;
+    if (mark.size() < (size_t)n_names || epoch + (uint32_t)n_edges + 1u >= (1u << 26)) {
+        mark.assign((size_t)n_names, 0u);
+        epoch = 0;
+    }
     for (int32_t q = 0; q < n_edges; ++q) {
-        const uint32_t tag = ((uint32_t)q + 1u) << 6;
+        const uint32_t tag = (++epoch) << 6;
         for (int d = 0; d < 4; ++d)
-            for (int64_t k = pt_off[4 * q + d]; k < pt_off[4 * q + d + 1]; ++k) {
+            for (int64_t k = pt_begin[4 * q + d]; k < pt_end[4 * q + d]; ++k) {
                 const int64_t rec = pt_rec[k];
                 if (rec < 0 || rec >= n_rec) return CORAL_ERR_ARG;
                 const int32_t nm = rec_name[rec];
@@ -303,7 +312,7 @@ extern "C" int coral_concordant_counts(int32_t n_edges, const int64_t *pt_off, c
             m |= 16u;                                          // supports a discordant edge at one of the two nodes
         }
         int64_t c = 0;
-        for (int64_t k = pt_off[4 * q]; k < pt_off[4 * q + 1]; ++k) {
+        for (int64_t k = pt_begin[4 * q]; k < pt_end[4 * q]; ++k) {
             uint32_t &m = mark[(size_t)rec_name[pt_rec[k]]];
             if ((m & 63u) == 15u) {                            // all four positions, no discordant support, not counted yet
                 ++c;

@@ -109,6 +109,8 @@ struct Entry {                                            // one (possibly pendi
     bool done = false, taken = false;                     // taken: some thread is computing it
     StepResult res;
     int64_t key[5];
+    double t_queued = 0, t_start = 0, t_end = 0;          // CORAL_SEARCH_PROFILE=2: when it was asked for / computed
+    int who = -1;                                         // -1 a worker, 0 the caller
 };
 
 struct KeyHash {
@@ -147,8 +149,8 @@ struct Search {
     bool stop = false;
     char err[256] = "";
     // CORAL_SEARCH_PROFILE=1: seconds per phase and work counters over all steps, printed when the handle is freed
-    bool profile = false;
-    int64_t par_min_reads = 24000, par_min_cands = 6000;      // a step splits work of at least this size over helper threads (CORAL_SEARCH_PAR_MIN: tests)
+    bool profile = false, profile_steps = false;
+    int64_t par_min_reads = 3000, par_min_cands = 2000;      // a step splits work of at least this size over helper threads (CORAL_SEARCH_PAR_MIN: tests)
     std::mutex pm;
     double t_reach = 0, t_union = 0, t_cand = 0, t_call = 0, t_wait = 0;
     long long n_steps = 0, n_visit = 0, n_adds = 0, n_keys = 0, n_union_items = 0, n_cand = 0, n_inline = 0;
@@ -455,7 +457,9 @@ void worker_main(Search *S) {
             if (e->taken) continue;                      // the caller got there first and computes it itself
             e->taken = true;
         }
+        e->t_start = now_s();
         compute_step(*S, T, e->key, e->res);
+        e->t_end = now_s();
         {
             std::lock_guard<std::mutex> lk(e->m);
             e->done = true;
@@ -512,6 +516,17 @@ struct BfsRun {
     const BfsParams &P;
     BfsOut &O;
     BfsRun(Search &s, const BfsParams &p, BfsOut &o) : S(s), P(p), O(o) {}
+    struct MemoHash {
+        size_t operator()(const std::array<int64_t, 3> &k) const {
+            uint64_t h = (uint64_t)k[0] * 0x9E3779B97F4A7C15ull;
+            h ^= ((uint64_t)k[1] + 0x7F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+            h ^= ((uint64_t)k[2] + 0x94D049BBull) * 0x94D049BB133111EBull;
+            return (size_t)(h ^ (h >> 29));
+        }
+    };
+    std::vector<std::shared_ptr<Entry>> held;
+    std::unordered_map<std::array<int64_t, 3>, std::array<int64_t, 2>, MemoHash> chunk_memo;     // (step result, run, call) -> chunk
+    double t_steps = 0;                                      // CORAL_SEARCH_PROFILE: seconds inside coral_search_step (waits included)
 
     int64_t nseg(int64_t t) const { return S.seg_off[t + 1] - S.seg_off[t]; }
     int64_t sstart(int64_t t, int64_t k) const { return S.seg_start[S.seg_off[t] + k]; }
@@ -590,8 +605,11 @@ struct BfsRun {
             const int64_t si = pos2cni(tid, s), ei = pos2cni(tid, e);
             if (si < 0 || ei < 0) continue;
             if (!P.tid_has_rows[tid]) { O.err_tid = tid; return BFS_ERR_KEY_CHROM; }
+            const double ts0 = S.profile ? now_s() : 0.0;
             int rc = coral_search_step(&S, tid, s, e, si, ei);
+            if (S.profile) t_steps += now_s() - ts0;
             if (rc != CORAL_OK) return rc;
+            if (S.current_entry) held.push_back(S.current_entry);      // (step results stay alive: chunk_memo is keyed by their address)
             std::shared_ptr<Entry> hold = S.current_entry;    // the result stays alive while later prefetches touch the cache
             const StepResult &R = *S.current;
             const size_t ng = R.groups.size() / 4;
@@ -613,14 +631,31 @@ struct BfsRun {
                     const int64_t head = calls.head[(size_t)q];
                     const int64_t *h = cand + 13 * head;
                     const int64_t f[11] = {h[0], calls.p1[(size_t)q], h[2], h[3], calls.p2[(size_t)q], h[5], h[6], h[7], h[8], h[9], h[10]};
-                    const int64_t c0 = (int64_t)O.chunk_read.size();
-                    for (int64_t u = calls.sup_off[(size_t)q]; u < calls.sup_off[(size_t)q + 1]; ++u) {
-                        const int64_t *m = cand + 13 * calls.sup_idx[(size_t)u];
-                        O.chunk_read.push_back(m[6]);
-                        O.chunk_i.push_back(m[7]);
-                        O.chunk_j.push_back(m[8]);
+                    // the support triples of (this step, this run, this call): written once — the search visits an interval as often
+                    // as it was queued (the reference's queue holds duplicates), and every visit unites the same supports again
+                    std::array<int64_t, 2> chunk;
+                    // (a step computed without look-ahead threads lives in the handle's one result slot: no stable identity, no memo)
+                    const bool memo = (bool)hold;
+                    const std::array<int64_t, 3> memo_key = {(int64_t)(intptr_t)hold.get(), (int64_t)gi, (int64_t)q};
+                    auto mit = memo ? chunk_memo.find(memo_key) : chunk_memo.end();
+                    if (mit != chunk_memo.end()) {
+                        chunk = mit->second;
+                    } else {
+                        const int64_t c0 = (int64_t)O.chunk_read.size();
+                        const int64_t u0 = calls.sup_off[(size_t)q], u1 = calls.sup_off[(size_t)q + 1];
+                        O.chunk_read.resize((size_t)(c0 + u1 - u0));
+                        O.chunk_i.resize((size_t)(c0 + u1 - u0));
+                        O.chunk_j.resize((size_t)(c0 + u1 - u0));
+                        for (int64_t u = u0; u < u1; ++u) {
+                            const int64_t *m = cand + 13 * calls.sup_idx[(size_t)u];
+                            O.chunk_read[(size_t)(c0 + u - u0)] = m[6];
+                            O.chunk_i[(size_t)(c0 + u - u0)] = m[7];
+                            O.chunk_j[(size_t)(c0 + u - u0)] = m[8];
+                        }
+                        chunk = {c0, c0 + u1 - u0};
+                        if (memo) chunk_memo.emplace(memo_key, chunk);
                     }
-                    const int64_t k = addbp(f, calls.stats.data() + 6 * (size_t)q, calls.flags[(size_t)q], ccid, {c0, (int64_t)O.chunk_read.size()});
+                    const int64_t k = addbp(f, calls.stats.data() + 6 * (size_t)q, calls.flags[(size_t)q], ccid, chunk);
                     if (std::find(found.begin(), found.end(), k) == found.end()) found.push_back(k);
                 }
                 struct In { int64_t cni, pos, k; };
@@ -854,7 +889,8 @@ extern "C" void *coral_search_create(int64_t n_reads, int64_t n_rows, const int6
         for (auto &x : th) x.join();
     }
     const char *pe = getenv("CORAL_SEARCH_PROFILE");
-    S->profile = pe && pe[0] == '1';
+    S->profile = pe && (pe[0] == '1' || pe[0] == '2');
+    S->profile_steps = pe && pe[0] == '2';
     if (const char *pm = getenv("CORAL_SEARCH_PAR_MIN")) S->par_min_reads = S->par_min_cands = atoll(pm);
     S->main_result.clear();
     S->current = &S->main_result;
@@ -912,6 +948,7 @@ extern "C" int coral_search_prefetch(void *h, int64_t tid, int64_t s, int64_t e,
     if (S.cache.find(key) != S.cache.end()) return CORAL_OK;
     auto ent = std::make_shared<Entry>();
     memcpy(ent->key, key.data(), sizeof(ent->key));
+    ent->t_queued = now_s();
     S.cache.emplace(key, ent);
     S.queue.push_back(ent);
     S.qcv.notify_one();
@@ -935,8 +972,12 @@ extern "C" int coral_search_step(void *h, int64_t tid, int64_t s, int64_t e, int
             std::unique_lock<std::mutex> lk(ent->m);
             if (!ent->taken) { ent->taken = true; mine = true; }           // still queued: do it here, the worker will skip it
         }
+        const double t_ask = now_s();
         if (mine) {
+            ent->t_start = t_ask;
+            ent->who = 0;
             compute_step(S, S.main_scratch, ent->key, ent->res);
+            ent->t_end = now_s();
             std::lock_guard<std::mutex> lk(ent->m);
             ent->done = true;
             ++S.n_inline;
@@ -946,6 +987,11 @@ extern "C" int coral_search_step(void *h, int64_t tid, int64_t s, int64_t e, int
             ent->cv.wait(lk, [&] { return ent->done; });
             if (S.profile) S.t_wait += now_s() - w0;
         }
+        if (S.profile_steps)
+            fprintf(stderr, "  step contig %lld [%lld, %lld]: queued %.2f ms before it was asked for, compute %.2f ms (%s), asked -> ready %.2f ms; "
+                    "%zu runs, %zu candidates, %zu reads in the runs\n", (long long)key[0], (long long)key[1], (long long)key[2],
+                    (t_ask - ent->t_queued) * 1e3, (ent->t_end - ent->t_start) * 1e3, ent->who == 0 ? "caller" : "worker", (now_s() - t_ask) * 1e3,
+                    ent->res.groups.size() / 4, ent->res.cand.size() / 13, ent->res.order.size());
         S.current_entry = ent;
         S.current = &ent->res;
     } else {
@@ -1068,6 +1114,7 @@ extern "C" int coral_search_bfs(void *h, int32_t n_seed, const int64_t *iv, cons
     }
     const BfsParams P{seg_cn, seg_ix, chr_rank, tid_has_rows, cn_gain, interval_delta, log_level >= 1, log_level >= 2};
     BfsRun run(S, P, O);
+    const double t_bfs0 = now_s();
     int rc = CORAL_OK;
     if (S.n_reads > 0)
         for (int32_t ai = 0; ai < n_seed && rc == CORAL_OK; ++ai) rc = run.enqueue(ai);
@@ -1077,6 +1124,8 @@ extern "C" int coral_search_bfs(void *h, int32_t n_seed, const int64_t *iv, cons
             rc = run.bfs_from(ai, ccid);
             ++ccid;
         }
+    if (S.profile) fprintf(stderr, "coral_search_bfs: %.2f ms in all, %.2f ms of it inside coral_search_step (waits for steps included), %zu support triples kept\n",
+                           (now_s() - t_bfs0) * 1e3, run.t_steps * 1e3, O.chunk_read.size());
     if (rc == BFS_ERR_KEY_CHROM) snprintf(S.err, sizeof(S.err), "search_bfs: KeyError contig %lld has no hashed alignments", (long long)O.err_tid);
     else if (rc == BFS_ERR_KEY_CHRIDX) snprintf(S.err, sizeof(S.err), "search_bfs: KeyError contig %lld outside chr1..22,X,Y,M", (long long)O.err_tid);
     else if (rc == BFS_ERR_INDEX) snprintf(S.err, sizeof(S.err), "search_bfs: segment index out of range");

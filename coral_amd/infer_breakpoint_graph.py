@@ -82,6 +82,34 @@ def interval_exclusive(a, lst):
     return hit, parts
 
 
+def rows_by_interval(r_tid, r_pos, r_end, intervals) -> np.ndarray:
+    """Indices of the records (contig, pos, end) overlapping each interval (tid, start, end inclusive) by the htslib rule
+    ``pos < e + 1 and end > s`` — interval by interval in list order, records in their own order within an interval, a record
+    in two intervals counting twice: the order in which ibg:750-766 meets them (Appendix A Q11)."""
+    g_tid, g_pos, g_end = (np.asarray(a).astype(np.int64) for a in (r_tid, r_pos, r_end))
+    ivs = np.array(intervals, dtype=np.int64).reshape(-1, 3)
+    if len(ivs) == 0 or len(g_tid) == 0:
+        return np.zeros(0, dtype=np.int64)
+    o = np.lexsort((ivs[:, 1], ivs[:, 0]))
+    srt = ivs[o]
+    disjoint = len(srt) < 2 or bool(((srt[1:, 0] != srt[:-1, 0]) | (srt[1:, 1] > srt[:-1, 2])).all())
+    if disjoint and bool((srt[:, 2] >= srt[:, 1]).all()) and int(srt[:, 2].max()) < (1 << 40) and int(srt[:, 1].min()) >= 0 and \
+            int(g_end.max()) < (1 << 40) and int(g_pos.min()) >= 0:
+        # the intervals of a contig are disjoint and sorted, so the ones a record overlaps are consecutive: two binary searches
+        # per record instead of a pass over all records per interval
+        key_lo = np.searchsorted((srt[:, 0] << 41) + srt[:, 2] + 1, (g_tid << 41) + g_pos, side="right")      # first with e + 1 > pos
+        key_hi = np.searchsorted((srt[:, 0] << 41) + srt[:, 1], (g_tid << 41) + g_end, side="left")           # first with s >= end
+        n_hit = np.maximum(key_hi - key_lo, 0)
+        rows = np.repeat(np.arange(len(g_tid)), n_hit)
+        within = np.arange(len(rows)) - np.repeat(np.cumsum(n_hit) - n_hit, n_hit)
+        ai = o[np.repeat(key_lo, n_hit) + within]
+        return rows[np.lexsort((rows, ai))]
+    parts = []
+    for t, s_, e_ in ivs.tolist():
+        parts.append(np.nonzero((g_tid == t) & (g_pos < e_ + 1) & (g_end > s_))[0])
+    return np.concatenate(parts)
+
+
 class _ChimericAlignments(dict):
     """``name -> (qint, rint(+cniset), qual, nm)`` exactly as the reference stores it (cp:269, ibg:200-210), over the
     ChimericTable: the keys (read names, in the reference's insertion order) are created the first time anything but the
@@ -1020,11 +1048,8 @@ class bam_to_breakpoint_nanopore():
         parts = []
         if len(g):
             g_rec = g[:, 0].astype(np.int64)
-            g_tid, g_pos, g_end = dr.h_tid[g_rec], dr.h_pos[g_rec], dr.h_end[g_rec]
-            for ai, iv in enumerate(self.amplicon_intervals):
-                t = self._tid_of[iv[0]]
-                m = (g_tid == t) & (g_pos < iv[2] + 1) & (g_end > iv[1])       # a record in two intervals counts twice (Q11)
-                parts.append(np.nonzero(m)[0])
+            ivs = [(self._tid_of[iv[0]], int(iv[1]), int(iv[2])) for iv in self.amplicon_intervals]
+            parts.append(rows_by_interval(dr.h_tid[g_rec], dr.h_pos[g_rec], dr.h_end[g_rec], ivs))
         sel = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
         cands = Candidates()
         if len(sel):
@@ -1145,19 +1170,16 @@ class bam_to_breakpoint_nanopore():
         for g, e in edges:
             t1, t2 = self._tid_of[e[0]], self._tid_of[e[3]]
             pts += [(t1, e[1]), (t2, e[4]), (t1, e[1] - cut - 1), (t2, e[4] + cut)]
-        cover = kernels.point_cover(self.rec, pts) if pts else []
+        cover = kernels.point_cover(self.rec, pts)
         if not edges:
             return
         nid = self.rec.h_name_id
         names = self.rec.names
-        # one native pass over all edges (coral_concordant_counts): the four fetches of an edge as record ordinals, the reads
-        # of the discordant edges at its two nodes as name ids
-        pt_off = np.zeros(4 * len(edges) + 1, dtype=np.int64)
-        np.cumsum([len(c) for c in cover], out=pt_off[1:])
-        pt_rec = np.ascontiguousarray(np.concatenate(cover), dtype=np.int64) if pt_off[-1] else np.zeros(0, dtype=np.int64)
+        # one native pass over all edges (coral_concordant_counts): the four fetches of an edge as slices of ONE array of record
+        # ordinals, the reads of the discordant edges at its two nodes as name ids
         sup_parts, sup_off, by_name = [], [0], {}
         for q, (g, e) in enumerate(edges):
-            e[9] = ReadNameSet(names, nid, cover[4 * q], cover[4 * q + 1])      # rls | rrs (ibg:1054) — name strings only on demand
+            e[9] = ReadNameSet(names, nid, cover[4 * q], cover[4 * q + 1], keep=cover)      # rls | rrs (ibg:1054) — name strings only on demand
             n_here = 0
             for node in ((e[0], e[1], e[2]), (e[3], e[4], e[5])):
                 for k in g.nodes[node][2]:
@@ -1173,9 +1195,11 @@ class bam_to_breakpoint_nanopore():
         sup_off = np.asarray(sup_off, dtype=np.int64)
         count = np.zeros(len(edges), dtype=np.int64)
         nid32 = np.ascontiguousarray(nid, dtype=np.int32)
-        _lib.check(_lib.lib().coral_concordant_counts(len(edges), pt_off.ctypes.data, pt_rec.ctypes.data, nid32.ctypes.data, len(nid32),
-                                                      self.rec.n_names, sup_off.ctypes.data, sup.ctypes.data, count.ctypes.data),
-                   "coral_concordant_counts")
+        pt_rec = np.ascontiguousarray(cover.rec, dtype=np.int32)
+        pt_begin, pt_end = np.ascontiguousarray(cover.begin, dtype=np.int64), np.ascontiguousarray(cover.end, dtype=np.int64)
+        _lib.check(_lib.lib().coral_concordant_counts(len(edges), pt_begin.ctypes.data, pt_end.ctypes.data, pt_rec.ctypes.data, len(pt_rec),
+                                                      nid32.ctypes.data, len(nid32), self.rec.n_names, sup_off.ctypes.data, sup.ctypes.data,
+                                                      count.ctypes.data), "coral_concordant_counts")
         for q, (g, e) in enumerate(edges):
             e[8] = int(count[q])
             if q in by_name:                                            # rare: redo this edge with the names themselves

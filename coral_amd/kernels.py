@@ -131,17 +131,14 @@ def _coverage_local(dr, scan: ScanResult, sg: np.ndarray) -> torch.Tensor:
     rs = dr.c_struct()
     strad = torch.empty(dr.n, dtype=torch.int32, device=dev)
     for batch in _disjoint_batches(sg):
-        b = sg[batch]
-        t = torch.tensor(b[:, 0], dtype=torch.int32, device=dev)
-        s = torch.tensor(b[:, 1], dtype=torch.int32, device=dev)
-        e = torch.tensor(b[:, 2], dtype=torch.int32, device=dev)
-        out = torch.zeros((2, len(batch)), dtype=torch.int64, device=dev)
-        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        tse = torch.from_numpy(np.ascontiguousarray(sg[batch].T, dtype=np.int32)).to(dev)      # one upload: rows = contig, start, end
+        out = torch.zeros((2, len(batch) + 1), dtype=torch.int64, device=dev)                  # (+ one column: the straddler counter)
+        cnt = out[0, len(batch):].view(torch.int32)
         _lib.check(L.coral_segment_coverage(C.byref(rs), scan.summary.data_ptr(), len(batch),
-                                            t.data_ptr(), s.data_ptr(), e.data_ptr(), out[0].data_ptr(),
+                                            tse[0].data_ptr(), tse[1].data_ptr(), tse[2].data_ptr(), out[0].data_ptr(),
                                             out[1].data_ptr(), strad.data_ptr(), cnt.data_ptr(), dr.stream()),
                    "coral_segment_coverage")
-        out_all[:, torch.tensor(batch, device=dev)] = out
+        out_all[:, torch.from_numpy(batch).to(dev)] = out[:, :len(batch)]
     return out_all
 
 
@@ -195,25 +192,60 @@ def _points_local(dr, uniq: np.ndarray, pair_cap: int) -> torch.Tensor:
         pair_cap = 1 << int(np.ceil(np.log2(k + 1)))
 
 
-def point_cover(dr, points: Sequence[Tuple[int, int]], pair_cap: int = 1 << 20, _worker=False) -> List[np.ndarray]:
+class PointCover:
+    """Result of ``point_cover``: for point j the record ordinals (file order) covering it are ``rec[begin[j]:end[j]]`` — ONE
+    int32 array for all points (equal points share their slice); ``cover[j]`` gives the slice."""
+
+    def __init__(self, rec: np.ndarray, begin: np.ndarray, end: np.ndarray, keep=None):
+        self.rec, self.begin, self.end, self._keep = rec, begin, end, keep
+
+    def __len__(self):
+        return len(self.begin)
+
+    def __getitem__(self, j):
+        return self.rec[self.begin[j]:self.end[j]]
+
+    def __iter__(self):
+        return (self[j] for j in range(len(self)))
+
+
+def point_cover(dr, points: Sequence[Tuple[int, int]], pair_cap: int = 0, _worker=False) -> PointCover:
     """For every (tid, pos) the ordinals (file order) of the records with pos <= p < end."""
     from . import sharding
     P = len(points)
     if P == 0:
-        return []
+        return PointCover(np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64))
     pts = np.asarray(points, dtype=np.int64).reshape(P, 2)
+    if not pair_cap:
+        pair_cap = getattr(dr, "_pair_cap_hint", 1 << 20)       # (what the last call on these records needed: one launch, not two)
     if dr.world > 1 and not _worker:
         sharding.command(dr, sharding.CMD_POINTS, (pair_cap,), payload=pts)
-    uniq, inverse = np.unique(pts, axis=0, return_inverse=True)     # sorted by (tid, pos)
+    # distinct points, sorted by (tid, pos): one int64 key per point
+    key = (pts[:, 0] << 32) | (pts[:, 1] & 0xFFFFFFFF) if bool((pts[:, 1] >= 0).all()) else None
+    if key is not None:
+        ukey, inverse = np.unique(key, return_inverse=True)
+        uniq = np.stack([ukey >> 32, ukey & 0xFFFFFFFF], axis=1)
+    else:
+        uniq, inverse = np.unique(pts, axis=0, return_inverse=True)
+    inverse = inverse.reshape(-1)
     pairs = _points_local(dr, uniq, pair_cap) + dr.lo                # record ordinal -> global
+    if pairs.numel() > pair_cap // 2 or pairs.numel() < pair_cap // 8:
+        dr._pair_cap_hint = max(1 << 16, 1 << int(np.ceil(np.log2(2 * pairs.numel() + 2))))
     if dr.world > 1:
         pairs = sharding.allgather_rows(dr, pairs[:, None])[:, 0]
-    keys = torch.sort(pairs).values.cpu().numpy()           # (point, record ordinal) order == fetch order per point
-    pt = keys >> 32
-    rec = (keys & 0xFFFFFFFF).astype(np.int64)
-    bounds = np.searchsorted(pt, np.arange(len(uniq) + 1))
-    per_uniq = [rec[bounds[j]:bounds[j + 1]] for j in range(len(uniq))]
-    return [per_uniq[j] for j in inverse.reshape(-1)]
+    keys = torch.sort(pairs).values                                   # (point, record ordinal) order == fetch order per point
+    # per-point slices are computed where the pairs are; only the int32 record ordinals and the small bounds cross to the host
+    bounds = torch.searchsorted(keys >> 32, torch.arange(len(uniq) + 1, dtype=torch.int64, device=keys.device))
+    rec32 = (keys & 0xFFFFFFFF).to(torch.int32)
+    keep = None
+    if rec32.is_cuda:
+        st = Staged(dr)
+        h = st.start("cover", dict(rec=rec32, bounds=bounds))
+        st.wait("cover")
+        rec, b, keep = h["rec"], h["bounds"], st
+    else:
+        rec, b = rec32.numpy(), bounds.numpy()
+    return PointCover(rec, b[:-1][inverse], b[1:][inverse], keep)
 
 
 class _PinnedPool:

@@ -175,15 +175,16 @@ class ReadSupportSet(_LazySet):
 class ReadNameSet(_LazySet):
     """``set`` of read names given as the record ordinals of the two point fetches whose union it is (``rls | rrs``, ibg:1054)
     and the records' name ids: materialised as ``set(names of the first) | set(names of the second)``, each in fetch order."""
-    __slots__ = ("_rec_name", "_left", "_right")
+    __slots__ = ("_rec_name", "_left", "_right", "_keep")
 
-    def __init__(self, names, rec_name, left_recs, right_recs):
+    def __init__(self, names, rec_name, left_recs, right_recs, keep=None):
         self._names = names
         self._set = None
         self._size = None
         self._rec_name = rec_name
         self._left = left_recs
         self._right = right_recs
+        self._keep = keep                 # owner of the memory the two record lists are views of
 
     def _ids(self, recs):
         return np.ascontiguousarray(self._rec_name[recs], dtype=np.int64)
@@ -192,7 +193,7 @@ class ReadNameSet(_LazySet):
         return set(self._names.take(self._ids(self._left))) | set(self._names.take(self._ids(self._right)))
 
     def _drop_arrays(self):
-        self._left = self._right = self._rec_name = None
+        self._left = self._right = self._rec_name = self._keep = None
 
     def _count(self):
         return len(self.name_ids())

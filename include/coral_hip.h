@@ -308,12 +308,14 @@ int coral_call_breakpoints(int64_t n, const int64_t *const *field_ptr, const int
 int coral_nm_stats(int64_t n, const int32_t *tid, const int64_t *sa_off, const int32_t *mapq, const int32_t *nm,
                    const int32_t *qlen, int64_t *count, double *sum_e, double *sum_e2);
 
-/* Long-read support of the concordant edges (ibg:1043-1055): for edge q, pt_rec[pt_off[4q + d] .. pt_off[4q + d + 1]) are the
- * record ordinals covering its position d (p, p + 1, p - 101, p + 101: coral_point_cover), rec_name int32[n_rec] maps records
- * to read-name ids, sup_name[sup_off[q] .. sup_off[q + 1]) are the name ids supporting a discordant edge at either node of the
- * edge; count[q] = number of distinct names covering all four positions and not among those.  Host arrays. */
-int coral_concordant_counts(int32_t n_edges, const int64_t *pt_off, const int64_t *pt_rec, const int32_t *rec_name, int64_t n_rec,
-                            int64_t n_names, const int64_t *sup_off, const int64_t *sup_name, int64_t *count);
+/* Long-read support of the concordant edges (ibg:1043-1055): for edge q, pt_rec[pt_begin[4q + d] .. pt_end[4q + d]) are the
+ * record ordinals covering its position d (p, p + 1, p - 101, p + 101: coral_point_cover; the four ranges may be any slices of
+ * the one int32 array pt_rec[n_pt_rec], equal points share theirs), rec_name int32[n_rec] maps records to read-name ids,
+ * sup_name[sup_off[q] .. sup_off[q + 1]) are the name ids supporting a discordant edge at either node of the edge;
+ * count[q] = number of distinct names covering all four positions and not among those.  Host arrays. */
+int coral_concordant_counts(int32_t n_edges, const int64_t *pt_begin, const int64_t *pt_end, const int32_t *pt_rec, int64_t n_pt_rec,
+                            const int32_t *rec_name, int64_t n_rec, int64_t n_names, const int64_t *sup_off, const int64_t *sup_name,
+                            int64_t *count);
 
 /* Reachable CN segments of one amplicon interval — the traversal of ibg:369-384 with the read-name sets replayed natively.
  * visit_rows[n_visit]: rows of the chimeric table hashed to segments si..ei of chromosome `tid`, in the reference's visiting

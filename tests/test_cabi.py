@@ -154,12 +154,22 @@ def test_concordant_counts_equal_python_sets():
         sets = [set(rec_name[l].tolist()) for l in lists]
         expect.append(len((sets[0] & sets[1] & sets[2] & sets[3]) - set(s_.tolist())))
     pt_off = np.concatenate([[0], np.cumsum([len(c) for c in cover])]).astype(np.int64)
-    pt_rec = np.concatenate(cover).astype(np.int64)
+    pt_rec = np.concatenate(cover).astype(np.int32)
+    pt_begin, pt_end = pt_off[:-1].copy(), pt_off[1:].copy()
+    for q in range(0, n_edges, 7):                 # equal points share ONE slice of the record array
+        pt_begin[4 * q + 2], pt_end[4 * q + 2] = pt_begin[4 * q], pt_end[4 * q]
     sup_off = np.concatenate([[0], np.cumsum([len(x) for x in sup])]).astype(np.int64)
     sup_all = np.concatenate(sup).astype(np.int64)
-    out = np.zeros(n_edges, dtype=np.int64)
-    assert _lib.lib().coral_concordant_counts(n_edges, pt_off.ctypes.data, pt_rec.ctypes.data, rec_name.ctypes.data, n_rec, n_names,
-                                              sup_off.ctypes.data, sup_all.ctypes.data, out.ctypes.data) == 0
+    L = _lib.lib()
+    for trial in range(3):                         # (the per-name marks live on between calls: repeated calls must not see stale ones)
+        out = np.zeros(n_edges, dtype=np.int64)
+        assert L.coral_concordant_counts(n_edges, pt_begin.ctypes.data, pt_end.ctypes.data, pt_rec.ctypes.data, len(pt_rec), rec_name.ctypes.data,
+                                         n_rec, n_names, sup_off.ctypes.data, sup_all.ctypes.data, out.ctypes.data) == 0
+        assert out.tolist() == expect
+    bad = pt_end.copy()
+    bad[5] = len(pt_rec) + 1
+    assert L.coral_concordant_counts(n_edges, pt_begin.ctypes.data, bad.ctypes.data, pt_rec.ctypes.data, len(pt_rec), rec_name.ctypes.data,
+                                     n_rec, n_names, sup_off.ctypes.data, sup_all.ctypes.data, out.ctypes.data) != 0
     assert out.tolist() == expect and sum(expect) > 50
 
 

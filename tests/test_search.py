@@ -133,3 +133,29 @@ def test_search_step_equals_single_queries(name, tmp_path, monkeypatch):
                 assert x[:3] == y[:3] and x[3].tolist() == y[3].tolist() and list(x[4]) == list(y[4])
                 assert [type(v) for v in x[4]] == [type(v) for v in y[4]]
     assert n_cand > 20
+
+
+def test_rows_by_interval_equals_the_per_interval_loop():
+    """The vectorised record-by-interval selection of find_smalldel_breakpoints (ibg:750-766) against the plain loop: same rows,
+    same order, records in two intervals twice; overlapping interval lists take the loop itself."""
+    import numpy as np
+    from coral_amd.infer_breakpoint_graph import rows_by_interval
+    rng = np.random.default_rng(4)
+    for trial in range(200):
+        n = int(rng.integers(0, 60))
+        tid = np.sort(rng.integers(0, 3, n))
+        pos = rng.integers(0, 5000, n)
+        end = pos + rng.integers(1, 1500, n)
+        k = int(rng.integers(0, 8))
+        ivs = []
+        if trial % 3:                      # disjoint per contig, in random list order
+            for t in range(3):
+                cuts = np.sort(rng.choice(7000, size=2 * int(rng.integers(0, 4)), replace=False))
+                ivs += [(t, int(cuts[2 * j]), int(cuts[2 * j + 1])) for j in range(len(cuts) // 2)]
+            ivs = [ivs[i] for i in rng.permutation(len(ivs))]
+        else:                              # arbitrary, overlapping
+            for _ in range(k):
+                s = int(rng.integers(0, 6000))
+                ivs.append((int(rng.integers(0, 3)), s, s + int(rng.integers(0, 2500))))
+        want = [i for (t, s, e) in ivs for i in range(n) if tid[i] == t and pos[i] < e + 1 and end[i] > s]
+        assert rows_by_interval(tid, pos, end, ivs).tolist() == want, (trial, ivs)

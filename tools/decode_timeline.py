@@ -14,7 +14,7 @@ out = open(sys.argv[2], "w") if len(sys.argv) > 2 else sys.stdout
 rows = []
 for f in glob.glob(d + "/**/*_kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]))
 rows.sort()
 infl = [r for r in rows if "k_bgzf_inflate" in r[2]]
 runs, cur = [], []
