@@ -4,9 +4,12 @@
 //                             /root/reference/src/breakpoint_utilities.py:268-282 with a per-cluster
 //                             set of *distinct* coordinates, so a cluster of N near-identical candidates
 //                             costs O(N * distinct) instead of O(N^2).
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
+#include <cmath>
 #include <exception>
 #include <unordered_map>
 #include <unordered_set>
@@ -342,5 +345,152 @@ extern "C" int coral_names_unify(int32_t n_pieces, const int64_t *n_names, const
     } catch (const std::exception &) {
         return CORAL_ERR_ARG;
     }
+    return CORAL_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// coral_cn_solve — the CN assignment of one amplicon graph: argmin Σ w_inv/x + w_lin·x − w_log·log x  s.t.  A x = 0, x > 0,
+// started at x = 1 (the convex program compute_cn_lr hands to cvxopt.solvers.cp, /root/reference/src/breakpoint_graph.py:495-606).
+// Infeasible-start Newton on the KKT system with a backtracking search on the KKT residual — the iteration of
+// coral_amd/breakpoint_graph.py:solve_cn_lr statement by statement (same formulas, same stopping rules), on the sparse balance
+// matrix (an edge touches at most two nodes: a column of A has at most two non-zeros), so that an iteration costs tens of
+// microseconds instead of a dozen numpy round trips.  A must have linearly independent rows (the caller drops the others).
+// Returns 0 = done (x filled), 1 = the reduced Newton system was singular at some iteration: the caller runs its general path.
+// ---------------------------------------------------------------------------------------------
+extern "C" int coral_cn_solve(int32_t n, int32_t p, const double *w_inv, const double *w_lin, const double *w_log, const double *A,
+                              int32_t max_iter, double *x_out, double *nu_out, int32_t *n_iter) {
+    if (n <= 0 || p < 0 || !w_inv || !w_lin || !w_log || (p > 0 && (!A || !nu_out)) || !x_out) return CORAL_ERR_ARG;
+    // columns of A as (row, value) lists
+    std::vector<int32_t> col_off((size_t)n + 1, 0);
+    std::vector<int32_t> col_row;
+    std::vector<double> col_val;
+    for (int32_t j = 0; j < n; ++j) {
+        for (int32_t i = 0; i < p; ++i)
+            if (A[(size_t)i * n + j] != 0.0) { col_row.push_back(i); col_val.push_back(A[(size_t)i * n + j]); }
+        col_off[(size_t)j + 1] = (int32_t)col_row.size();
+    }
+    std::vector<double> x((size_t)n, 1.0), nu((size_t)p, 0.0), r((size_t)n + p), r_new((size_t)n + p), h((size_t)n), dx((size_t)n), dnu((size_t)p),
+        xt((size_t)n), nut((size_t)p), hinv((size_t)n);
+    auto residual = [&](const std::vector<double> &xv, const std::vector<double> &nv, std::vector<double> &out) {
+        for (int32_t i = 0; i < p; ++i) out[(size_t)n + i] = 0.0;
+        for (int32_t j = 0; j < n; ++j) {
+            double atnu = 0.0;
+            for (int32_t q = col_off[(size_t)j]; q < col_off[(size_t)j + 1]; ++q) {
+                atnu += col_val[(size_t)q] * nv[(size_t)col_row[(size_t)q]];
+                out[(size_t)n + col_row[(size_t)q]] += col_val[(size_t)q] * xv[(size_t)j];
+            }
+            out[(size_t)j] = w_lin[j] - w_log[j] / xv[(size_t)j] - w_inv[j] / (xv[(size_t)j] * xv[(size_t)j]) + atnu;
+        }
+    };
+    auto norm = [&](const std::vector<double> &v) {
+        double s = 0.0;
+        for (double e : v) s += e * e;
+        return sqrt(s);
+    };
+    std::vector<int32_t> zero;
+    std::vector<double> M, rhs;
+    residual(x, nu, r);
+    int32_t it = 0;
+    for (; it < max_iter; ++it) {
+        zero.clear();
+        for (int32_t j = 0; j < n; ++j) {
+            h[(size_t)j] = w_log[j] / (x[(size_t)j] * x[(size_t)j]) + 2.0 * w_inv[j] / (x[(size_t)j] * x[(size_t)j] * x[(size_t)j]);
+            if (h[(size_t)j] > 0) hinv[(size_t)j] = 1.0 / h[(size_t)j];
+            else { hinv[(size_t)j] = 0.0; zero.push_back(j); }
+        }
+        const int32_t nz = (int32_t)zero.size(), m = p + nz;
+        // M = [[S, -Az], [Azᵀ, 0]],  S = Σ_j hinv_j a_j a_jᵀ over the columns with h > 0;  rhs = [rp − Ap (hinv ∘ rd_p); −rd_z]
+        M.assign((size_t)m * m, 0.0);
+        rhs.assign((size_t)m, 0.0);
+        for (int32_t i = 0; i < p; ++i) rhs[(size_t)i] = r[(size_t)n + i];
+        for (int32_t j = 0; j < n; ++j) {
+            if (!(h[(size_t)j] > 0)) continue;
+            const double w = hinv[(size_t)j];
+            for (int32_t q = col_off[(size_t)j]; q < col_off[(size_t)j + 1]; ++q) {
+                const int32_t a = col_row[(size_t)q];
+                rhs[(size_t)a] -= col_val[(size_t)q] * (w * r[(size_t)j]);
+                for (int32_t q2 = col_off[(size_t)j]; q2 < col_off[(size_t)j + 1]; ++q2)
+                    M[(size_t)a * m + col_row[(size_t)q2]] += (col_val[(size_t)q] * w) * col_val[(size_t)q2];
+            }
+        }
+        for (int32_t k = 0; k < nz; ++k) {
+            const int32_t j = zero[(size_t)k];
+            for (int32_t q = col_off[(size_t)j]; q < col_off[(size_t)j + 1]; ++q) {
+                M[(size_t)col_row[(size_t)q] * m + p + k] = -col_val[(size_t)q];
+                M[(size_t)(p + k) * m + col_row[(size_t)q]] = col_val[(size_t)q];
+            }
+            rhs[(size_t)p + k] = -r[(size_t)j];
+        }
+        // Gaussian elimination with partial pivoting
+        bool singular = false;
+        for (int32_t c = 0; c < m && !singular; ++c) {
+            int32_t piv = c;
+            double best = fabs(M[(size_t)c * m + c]);
+            for (int32_t i = c + 1; i < m; ++i)
+                if (fabs(M[(size_t)i * m + c]) > best) { best = fabs(M[(size_t)i * m + c]); piv = i; }
+            if (!(best > 0.0) || !std::isfinite(best)) { singular = true; break; }
+            if (piv != c) {
+                for (int32_t k = c; k < m; ++k) std::swap(M[(size_t)c * m + k], M[(size_t)piv * m + k]);
+                std::swap(rhs[(size_t)c], rhs[(size_t)piv]);
+            }
+            const double d = M[(size_t)c * m + c];
+            for (int32_t i = c + 1; i < m; ++i) {
+                const double f = M[(size_t)i * m + c] / d;
+                if (f == 0.0) continue;
+                double *ri = &M[(size_t)i * m], *rc = &M[(size_t)c * m];
+                for (int32_t k = c + 1; k < m; ++k) ri[k] -= f * rc[k];
+                rhs[(size_t)i] -= f * rhs[(size_t)c];
+            }
+        }
+        if (singular) return 1;
+        for (int32_t c = m - 1; c >= 0; --c) {
+            double s = rhs[(size_t)c];
+            for (int32_t k = c + 1; k < m; ++k) s -= M[(size_t)c * m + k] * rhs[(size_t)k];
+            rhs[(size_t)c] = s / M[(size_t)c * m + c];
+            if (!std::isfinite(rhs[(size_t)c])) return 1;
+        }
+        for (int32_t i = 0; i < p; ++i) dnu[(size_t)i] = rhs[(size_t)i];
+        for (int32_t j = 0; j < n; ++j) {
+            if (!(h[(size_t)j] > 0)) continue;
+            double atdnu = 0.0;
+            for (int32_t q = col_off[(size_t)j]; q < col_off[(size_t)j + 1]; ++q) atdnu += col_val[(size_t)q] * dnu[(size_t)col_row[(size_t)q]];
+            dx[(size_t)j] = -(r[(size_t)j] + atdnu) * hinv[(size_t)j];
+        }
+        for (int32_t k = 0; k < nz; ++k) dx[(size_t)zero[(size_t)k]] = rhs[(size_t)p + k];
+        double t = 1.0;
+        bool any = false;
+        double lim = 0.0;
+        for (int32_t j = 0; j < n; ++j)
+            if (dx[(size_t)j] < 0) {
+                const double v = -x[(size_t)j] / dx[(size_t)j];
+                if (!any || v < lim) lim = v;
+                any = true;
+            }
+        if (any) t = std::min(1.0, 0.99 * lim);
+        const double r0 = norm(r);
+        bool improved = false;
+        while (t > 1e-10) {
+            for (int32_t j = 0; j < n; ++j) xt[(size_t)j] = x[(size_t)j] + t * dx[(size_t)j];
+            for (int32_t i = 0; i < p; ++i) nut[(size_t)i] = nu[(size_t)i] + t * dnu[(size_t)i];
+            residual(xt, nut, r_new);
+            if (norm(r_new) <= (1.0 - 0.01 * t) * r0) { improved = true; break; }
+            t *= 0.5;
+        }
+        double rel = 0.0;
+        for (int32_t j = 0; j < n; ++j) rel = std::max(rel, fabs(dx[(size_t)j]) / x[(size_t)j]);
+        const bool small = rel < 1e-13;
+        if (!improved) {
+            if (small) for (int32_t j = 0; j < n; ++j) x[(size_t)j] += dx[(size_t)j];      // at the float64 floor: the (tiny) full step, then stop
+            break;
+        }
+        x.swap(xt);
+        nu.swap(nut);
+        r.swap(r_new);
+        if (small) break;
+    }
+    for (int32_t j = 0; j < n; ++j) x_out[j] = x[(size_t)j];
+    for (int32_t i = 0; i < p; ++i) nu_out[i] = nu[(size_t)i];
+    if (n_iter) *n_iter = it;
     return CORAL_OK;
 }

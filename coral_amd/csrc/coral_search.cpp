@@ -70,6 +70,7 @@ struct StepResult {
     // the same, flattened for one-shot retrieval (coral_search_result): see the header for the layout of `meta`
     std::vector<int64_t> meta, sup;
     std::vector<double> stats;
+    double t_phase[4] = {0, 0, 0, 0};                      // CORAL_SEARCH_PROFILE: reach, union, candidates, calls (seconds, wall)
     void clear() {
         rc = CORAL_OK; err[0] = 0;
         groups.clear(); cand.clear(); order.clear(); order_off.assign(1, 0); calls.clear();
@@ -407,6 +408,7 @@ void compute_step(Search &S, Scratch &T, const int64_t key[5], StepResult &R) {
     R.flatten();
     if (S.profile) {
         const double t3 = now_s();
+        R.t_phase[0] = t1 - t0; R.t_phase[1] = t_u; R.t_phase[2] = t_c; R.t_phase[3] = t3 - t2;
         std::lock_guard<std::mutex> lk(S.pm);
         S.t_reach += t1 - t0; S.t_union += t_u; S.t_cand += t_c; S.t_call += t3 - t2;
         ++S.n_steps; S.n_visit += n_visit; S.n_adds += n_adds; S.n_keys += (long long)codes.size(); S.n_union_items += n_items;
@@ -989,9 +991,10 @@ extern "C" int coral_search_step(void *h, int64_t tid, int64_t s, int64_t e, int
         }
         if (S.profile_steps)
             fprintf(stderr, "  step contig %lld [%lld, %lld]: queued %.2f ms before it was asked for, compute %.2f ms (%s), asked -> ready %.2f ms; "
-                    "%zu runs, %zu candidates, %zu reads in the runs\n", (long long)key[0], (long long)key[1], (long long)key[2],
+                    "%zu runs, %zu candidates, %zu reads in the runs; reach %.2f union %.2f candidates %.2f calls %.2f ms\n", (long long)key[0], (long long)key[1], (long long)key[2],
                     (t_ask - ent->t_queued) * 1e3, (ent->t_end - ent->t_start) * 1e3, ent->who == 0 ? "caller" : "worker", (now_s() - t_ask) * 1e3,
-                    ent->res.groups.size() / 4, ent->res.cand.size() / 13, ent->res.order.size());
+                    ent->res.groups.size() / 4, ent->res.cand.size() / 13, ent->res.order.size(), ent->res.t_phase[0] * 1e3, ent->res.t_phase[1] * 1e3,
+                    ent->res.t_phase[2] * 1e3, ent->res.t_phase[3] * 1e3);
         S.current_entry = ent;
         S.current = &ent->res;
     } else {

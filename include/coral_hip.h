@@ -317,6 +317,15 @@ int coral_concordant_counts(int32_t n_edges, const int64_t *pt_begin, const int6
                             const int32_t *rec_name, int64_t n_rec, int64_t n_names, const int64_t *sup_off, const int64_t *sup_name,
                             int64_t *count);
 
+/* coral_cn_solve — HOST function: the CN assignment of one amplicon graph,  argmin Σ w_inv/x + w_lin·x − w_log·log x  s.t.
+ * A x = 0, x > 0,  started at x = 1 — the convex program compute_cn_lr gives to cvxopt.solvers.cp
+ * (/root/reference/src/breakpoint_graph.py:495-606; one variable per edge, one balance row per interior node).  A double[p][n]
+ * row-major with linearly independent rows.  Infeasible-start Newton with a backtracking search on the KKT residual, until the
+ * relative step is below 1e-13.  Returns 0 (x[n] and nu[p] filled, *n_iter = iterations), 1 = the reduced Newton system was singular
+ * (the caller takes its general path), negative = bad arguments.  CN parity against cvxopt itself is unpinned. */
+int coral_cn_solve(int32_t n, int32_t p, const double *w_inv, const double *w_lin, const double *w_log, const double *A,
+                   int32_t max_iter, double *x, double *nu /* [p]: the multipliers of the balance rows */, int32_t *n_iter);
+
 /* Reachable CN segments of one amplicon interval — the traversal of ibg:369-384 with the read-name sets replayed natively.
  * visit_rows[n_visit]: rows of the chimeric table hashed to segments si..ei of chromosome `tid`, in the reference's visiting
  * order (segment ascending, then append order).  row_read/row_tid/cni0/cni1 are per table row, off[n_reads + 1] the row
