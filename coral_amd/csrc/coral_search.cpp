@@ -348,6 +348,7 @@ void compute_step(Search &S, Scratch &T, const int64_t key[5], StepResult &R) {
             if (acc.key[slot_e] >= 0) R.order.push_back(acc.key[slot_e]);
         const int32_t *ord = R.order.data() + order_before;
         const size_t n_ord = R.order.size() - order_before;
+        const double tu1b = S.profile ? now_s() : 0.0;
         // alignment2bp of every read of the run, in the set's iteration order.  A big run is cut into consecutive chunks of reads
         // that helper threads filter into lists of their own; the lists are appended in chunk order, so the result is the one
         // a single pass gives (a step is on the search's critical path: the breadth-first search waits for it)
@@ -360,6 +361,7 @@ void compute_step(Search &S, Scratch &T, const int64_t key[5], StepResult &R) {
             }
             return ok;
         };
+        double t_main = 0.0;
         if (helpers == 0) {
             contigs_ok &= filter(0, n_ord, T, R.cand);
         } else {
@@ -371,6 +373,7 @@ void compute_step(Search &S, Scratch &T, const int64_t key[5], StepResult &R) {
             for (int h = 0; h < helpers; ++h)
                 th.emplace_back([&, h]() { okv[(size_t)h] = filter(per * (size_t)(h + 1), h + 1 == helpers ? n_ord : per * (size_t)(h + 2), scr[(size_t)h], part[(size_t)h]); });
             contigs_ok &= filter(0, per, T, R.cand);
+            t_main = S.profile ? now_s() - tu1b : 0.0;
             for (int h = 0; h < helpers; ++h) {
                 th[(size_t)h].join();
                 contigs_ok &= okv[(size_t)h] != 0;
@@ -384,6 +387,9 @@ void compute_step(Search &S, Scratch &T, const int64_t key[5], StepResult &R) {
         const double tu2 = S.profile ? now_s() : 0.0;
         t_u += tu1 - tu0;
         t_c += tu2 - tu1;
+        if (S.profile_steps)
+            fprintf(stderr, "      run of %zu reads: set order %.3f ms, filter %.3f ms (%d helpers; this thread's quarter incl. spawning them %.3f ms), %lld candidates\n",
+                    n_ord, (tu1b - tu1) * 1e3, (tu2 - tu1b) * 1e3, helpers, t_main * 1e3, (long long)n_c);
     }
     const double t2 = S.profile ? now_s() : 0.0;
     if (!contigs_ok) return fail(CORAL_ERR_FORMAT, "search_step: contig outside chr1..22,X,Y,M");
