@@ -24,9 +24,11 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -122,9 +124,71 @@ struct KeyHash {
     }
 };
 
+// A small work-sharing pool: a caller hands in a batch of tasks, helps to run tasks (its own or another caller's) while it
+// waits, and returns when its batch is done.  Several steps may be computed at once (one per look-ahead thread), each handing
+// in its batches; the helpers sleep on a condition variable between batches.
+struct TaskPool {
+    struct Task { std::function<void()> *fn; std::atomic<int> *left; };
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Task> q;
+    bool stop = false;
+    std::vector<std::thread> th;
+    explicit TaskPool(int n) {
+        for (int k = 0; k < n; ++k)
+            th.emplace_back([this]() {
+                for (;;) {
+                    Task t;
+                    {
+                        std::unique_lock<std::mutex> lk(m);
+                        cv.wait(lk, [&] { return stop || !q.empty(); });
+                        if (q.empty()) return;
+                        t = q.front();
+                        q.pop_front();
+                    }
+                    (*t.fn)();
+                    t.left->fetch_sub(1, std::memory_order_acq_rel);
+                }
+            });
+    }
+    ~TaskPool() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto &x : th) x.join();
+    }
+    void run(std::vector<std::function<void()>> &tasks) {
+        if (tasks.empty()) return;
+        std::atomic<int> left((int)tasks.size());
+        {
+            std::lock_guard<std::mutex> lk(m);
+            for (size_t k = 1; k < tasks.size(); ++k) q.push_back(Task{&tasks[k], &left});
+        }
+        cv.notify_all();
+        tasks[0]();
+        left.fetch_sub(1, std::memory_order_acq_rel);
+        while (left.load(std::memory_order_acquire) > 0) {
+            Task t{nullptr, nullptr};
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (!q.empty()) { t = q.front(); q.pop_front(); }
+            }
+            if (t.fn) {
+                (*t.fn)();
+                t.left->fetch_sub(1, std::memory_order_acq_rel);
+            } else {
+                std::this_thread::yield();
+            }
+        }
+    }
+};
+
 struct BfsOut;
 
 struct Search {
+    std::unique_ptr<TaskPool> pool;                       // helpers of big steps (coral_search_params: with the look-ahead threads)
     std::shared_ptr<BfsOut> bfs;                          // result of the last coral_search_bfs
     int64_t n_reads = 0, n_rows = 0, n_ent = 0;
     const int64_t *off = nullptr, *row_read = nullptr, *read_hash = nullptr, *read_name = nullptr, *e_key = nullptr, *e_row = nullptr;
@@ -329,88 +393,104 @@ void compute_step(Search &S, Scratch &T, const int64_t key[5], StepResult &R) {
         if (cur.b1 >= n_seg || cur.b0 >= n_seg) return fail(CORAL_ERR_ARG, "search_step: segment index out of range");
         plan.push_back(cur);
     }
-    // ---- per run: iteration order of  set() | sets[k0] | sets[k1] | ...  then alignment2bp of every read (bu:70-96)
-    bool contigs_ok = true;
-    double t_u = 0.0, t_c = 0.0;
+    // ---- per run: iteration order of  set() | sets[k0] | sets[k1] | ...  then alignment2bp of every read (bu:70-96), then
+    // cluster_bp_list + the bpc2bp loop (ibg:436-457: the sub-cluster counter never advances there, Q4).  A step is on the
+    // search's critical path (the breadth-first search often needs it the moment it discovers the interval), and the runs of a
+    // step are independent of each other, so the three stages go through the handle's task pool when the step is big enough:
+    //   A  per run: the union of its sets and the union's iteration order;
+    //   B  per (run, chunk of consecutive reads): the pair filter into a list of its own;
+    //   C  per run: its chunks' lists appended in chunk order (= the list a single pass gives) and the breakpoint calls.
+    const size_t n_runs = plan.size();
+    R.calls.resize(n_runs);
+    std::vector<std::vector<int32_t>> order_of(n_runs);
     long long n_items = 0;
-    R.calls.resize(plan.size());
-    for (size_t g = 0; g < plan.size(); ++g) {
-        const Run &run = plan[g];
-        const double tu0 = S.profile ? now_s() : 0.0;
+    const double tA0 = S.profile ? now_s() : 0.0;
+    auto stage_a = [&](size_t g) {
         PySetEmu acc;
-        for (int32_t k : run.keys) acc.merge(sets[(size_t)k]);
-        const double tu1 = S.profile ? now_s() : 0.0;
-        n_items += (long long)acc.used;
-        const int64_t t1_ = run.t, s1 = S.seg_start[S.seg_off[run.t] + run.b0], e1 = S.seg_end[S.seg_off[run.t] + run.b1];
-        const size_t cand_before = R.cand.size(), order_before = R.order.size();
-        R.order.reserve(order_before + acc.used);
+        for (int32_t k : plan[g].keys) acc.merge(sets[(size_t)k]);
+        std::vector<int32_t> &ord = order_of[g];
+        ord.reserve(acc.used);
         for (size_t slot_e = 0; slot_e <= acc.mask; ++slot_e)
-            if (acc.key[slot_e] >= 0) R.order.push_back(acc.key[slot_e]);
-        const int32_t *ord = R.order.data() + order_before;
-        const size_t n_ord = R.order.size() - order_before;
-        const double tu1b = S.profile ? now_s() : 0.0;
-        // alignment2bp of every read of the run, in the set's iteration order.  A big run is cut into consecutive chunks of reads
-        // that helper threads filter into lists of their own; the lists are appended in chunk order, so the result is the one
-        // a single pass gives (a step is on the search's critical path: the breadth-first search waits for it)
-        const int helpers = (int64_t)n_ord >= S.par_min_reads && n_ord >= 8 ? 3 : 0;
-        auto filter = [&](size_t q0, size_t q1, Scratch &sc, std::vector<int64_t> &dst) {
-            bool ok = true;
-            for (size_t q = q0; q < q1; ++q) {
-                if (q + 6 < q1) __builtin_prefetch(S.pack.data() + S.pack_off[(size_t)ord[q + 6]]);
-                ok &= pairs_between(S, sc, dst, ord[q], t1_, s1, e1, tid, s, e);
-            }
-            return ok;
-        };
-        double t_main = 0.0;
-        if (helpers == 0) {
-            contigs_ok &= filter(0, n_ord, T, R.cand);
-        } else {
-            std::vector<std::vector<int64_t>> part((size_t)helpers);
-            std::vector<Scratch> scr((size_t)helpers);
-            std::vector<char> okv((size_t)helpers, 1);
-            std::vector<std::thread> th;
-            const size_t per = n_ord / (size_t)(helpers + 1);
-            for (int h = 0; h < helpers; ++h)
-                th.emplace_back([&, h]() { okv[(size_t)h] = filter(per * (size_t)(h + 1), h + 1 == helpers ? n_ord : per * (size_t)(h + 2), scr[(size_t)h], part[(size_t)h]); });
-            contigs_ok &= filter(0, per, T, R.cand);
-            t_main = S.profile ? now_s() - tu1b : 0.0;
-            for (int h = 0; h < helpers; ++h) {
-                th[(size_t)h].join();
-                contigs_ok &= okv[(size_t)h] != 0;
-                R.cand.insert(R.cand.end(), part[(size_t)h].begin(), part[(size_t)h].end());
-            }
+            if (acc.key[slot_e] >= 0) ord.push_back(acc.key[slot_e]);
+    };
+    int64_t reads_in_sets = 0;
+    for (size_t g = 0; g < n_runs; ++g)
+        for (int32_t k : plan[g].keys) reads_in_sets += (int64_t)sets[(size_t)k].used;
+    const bool pooled = S.pool && reads_in_sets >= S.par_min_reads;
+    if (pooled && n_runs > 1) {
+        std::vector<std::function<void()>> tasks;
+        for (size_t g = 0; g < n_runs; ++g) tasks.emplace_back([&, g]() { stage_a(g); });
+        S.pool->run(tasks);
+    } else {
+        for (size_t g = 0; g < n_runs; ++g) stage_a(g);
+    }
+    for (size_t g = 0; g < n_runs; ++g) n_items += (long long)order_of[g].size();
+    const double tB0 = S.profile ? now_s() : 0.0;
+    // stage B: chunks of ~2 000 reads (at most 8 per run)
+    struct Chunk { size_t g, q0, q1; std::vector<int64_t> cand; bool ok = true; };
+    std::vector<Chunk> chunks;
+    for (size_t g = 0; g < n_runs; ++g) {
+        const size_t n_ord = order_of[g].size();
+        const size_t pieces = pooled ? std::max<size_t>(1, std::min<size_t>(8, n_ord / 2000)) : 1;
+        for (size_t c = 0; c < pieces; ++c) chunks.push_back(Chunk{g, n_ord * c / pieces, n_ord * (c + 1) / pieces, {}, true});
+    }
+    auto stage_b = [&](Chunk &ch, Scratch &sc) {
+        const Run &run = plan[ch.g];
+        const int64_t t1_ = run.t, s1 = S.seg_start[S.seg_off[run.t] + run.b0], e1 = S.seg_end[S.seg_off[run.t] + run.b1];
+        const int32_t *ord = order_of[ch.g].data();
+        for (size_t q = ch.q0; q < ch.q1; ++q) {
+            if (q + 6 < ch.q1) __builtin_prefetch(S.pack.data() + S.pack_off[(size_t)ord[q + 6]]);
+            ch.ok &= pairs_between(S, sc, ch.cand, ord[q], t1_, s1, e1, tid, s, e);
         }
+    };
+    if (pooled && chunks.size() > 1) {
+        std::vector<std::function<void()>> tasks;
+        for (size_t c = 0; c < chunks.size(); ++c)
+            tasks.emplace_back([&, c]() {
+                Scratch sc;                                  // (pairs_between only uses the `used` marks: a few bytes)
+                stage_b(chunks[c], sc);
+            });
+        S.pool->run(tasks);
+    } else {
+        for (Chunk &ch : chunks) stage_b(ch, T);
+    }
+    const double tC0 = S.profile ? now_s() : 0.0;
+    bool contigs_ok = true;
+    std::vector<int64_t> at(n_runs + 1, 0);
+    for (const Chunk &ch : chunks) {
+        at[ch.g + 1] += (int64_t)(ch.cand.size() / 13);
+        contigs_ok &= ch.ok;
+    }
+    for (size_t g = 0; g < n_runs; ++g) at[g + 1] += at[g];
+    R.cand.resize((size_t)at[n_runs] * 13);
+    {
+        std::vector<int64_t> w(at.begin(), at.end() - 1);
+        for (const Chunk &ch : chunks) {
+            if (!ch.cand.empty()) memcpy(R.cand.data() + 13 * w[ch.g], ch.cand.data(), ch.cand.size() * sizeof(int64_t));
+            w[ch.g] += (int64_t)(ch.cand.size() / 13);
+        }
+    }
+    for (size_t g = 0; g < n_runs; ++g) {
+        R.order.insert(R.order.end(), order_of[g].begin(), order_of[g].end());
         R.order_off.push_back((int64_t)R.order.size());
-        const int64_t n_c = (int64_t)((R.cand.size() - cand_before) / 13);
-        const int64_t gr[4] = {run.t, run.b0, run.b1, n_c};
+        const int64_t gr[4] = {plan[g].t, plan[g].b0, plan[g].b1, at[g + 1] - at[g]};
         R.groups.insert(R.groups.end(), gr, gr + 4);
-        const double tu2 = S.profile ? now_s() : 0.0;
-        t_u += tu1 - tu0;
-        t_c += tu2 - tu1;
-        if (S.profile_steps)
-            fprintf(stderr, "      run of %zu reads: set order %.3f ms, filter %.3f ms (%d helpers; this thread's quarter incl. spawning them %.3f ms), %lld candidates\n",
-                    n_ord, (tu1b - tu1) * 1e3, (tu2 - tu1b) * 1e3, helpers, t_main * 1e3, (long long)n_c);
     }
     const double t2 = S.profile ? now_s() : 0.0;
     if (!contigs_ok) return fail(CORAL_ERR_FORMAT, "search_step: contig outside chr1..22,X,Y,M");
-    // ---- cluster_bp_list + the bpc2bp loop of every run (ibg:436-457: the sub-cluster counter never advances there, Q4)
     {
-        std::vector<int64_t> at(plan.size() + 1, 0);
-        for (size_t g = 0; g < plan.size(); ++g) at[g + 1] = at[g] + R.groups[4 * g + 3];
-        // runs are independent: the big ones on helper threads (largest first), the rest here
-        std::vector<size_t> big;
-        for (size_t g = 0; g < plan.size(); ++g)
-            if (R.groups[4 * g + 3] >= S.par_min_cands) big.push_back(g);
-        std::sort(big.begin(), big.end(), [&](size_t a, size_t b) { return R.groups[4 * a + 3] > R.groups[4 * b + 3]; });
-        if (big.size() > 4) big.resize(4);
-        if (big.size() < 2) big.clear();
-        std::vector<std::thread> th;
-        for (size_t k = 1; k < big.size(); ++k)
-            th.emplace_back([&, k]() { run_calls(S, R.cand.data() + 13 * at[big[k]], R.groups[4 * big[k] + 3], R.calls[big[k]]); });
-        for (size_t g = 0; g < plan.size(); ++g)
-            if (std::find(big.begin() + (big.empty() ? 0 : 1), big.end(), g) == big.end()) run_calls(S, R.cand.data() + 13 * at[g], R.groups[4 * g + 3], R.calls[g]);
-        for (auto &x : th) x.join();
+        size_t n_big = 0;
+        for (size_t g = 0; g < n_runs; ++g) n_big += (at[g + 1] - at[g]) >= S.par_min_cands ? 1 : 0;
+        if (pooled && n_big > 1) {
+            std::vector<std::function<void()>> tasks;
+            for (size_t g = 0; g < n_runs; ++g) tasks.emplace_back([&, g]() { run_calls(S, R.cand.data() + 13 * at[g], at[g + 1] - at[g], R.calls[g]); });
+            S.pool->run(tasks);
+        } else {
+            for (size_t g = 0; g < n_runs; ++g) run_calls(S, R.cand.data() + 13 * at[g], at[g + 1] - at[g], R.calls[g]);
+        }
     }
+    const double t_u = tB0 - tA0, t_c = t2 - tB0;
+    (void)tC0;
     R.flatten();
     if (S.profile) {
         const double t3 = now_s();
@@ -913,6 +993,7 @@ extern "C" int coral_search_params(void *h, double min_cluster_cutoff, int64_t m
     if (!S.workers.empty() || !S.cache.empty()) return CORAL_ERR_ARG;          // set once, before the first step
     S.min_cluster_cutoff = min_cluster_cutoff; S.max_seq_len = max_seq_len; S.bp_distance_cutoff = bp_distance_cutoff;
     S.match_cutoff = match_cutoff; S.accept_floor = accept_floor;
+    if (n_threads > 0) S.pool.reset(new TaskPool(3));
     const std::vector<int> cpus = n_threads > 0 ? cpus_of_my_node() : std::vector<int>();
     for (int32_t k = 0; k < n_threads; ++k) {
         S.workers.emplace_back(worker_main, &S);
