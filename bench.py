@@ -189,7 +189,10 @@ def main():
                        # the order-sensitive host logic of rank 0 does not
                        "serial_ms": round(ms_per_step - scan_ms_avg, 1),
                        "phase_ms_median": {k: round(sorted(p.get(k, 0.0) for p in phases)[len(phases) // 2] * 1e3, 1)
-                                           for k in (phases[-1] if phases else {})}},
+                                           for k in (phases[-1] if phases else {})},
+                       # (where the slowest timed step lost its time: steps are host-bound, so scheduling noise of the box shows)
+                       "slowest_step_phase_ms": {k: round(v * 1e3, 1) for k, v in
+                                                 (phases[max(range(len(step_ms)), key=step_ms.__getitem__)] if phases else {}).items()}},
             "roofline": {"bound": "hbm", "kernel": scan_kernel, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": pmc_traffic(cfg, world, _lib.lib().coral_version().decode()), "launch_ms": scan_ms_avg,
                          "algorithmic_bytes_per_launch": int(alg_bytes_local)},
@@ -335,8 +338,7 @@ def bam_legs(a, rank, world, dev, work, rec=None):
             torch.cuda.synchronize()
             runs.append((time.perf_counter() - t0, dict(bam.LAST_DECODE)))
             assert whole.n == n_records
-            del whole
-            torch.cuda.empty_cache()
+            del whole                                  # (its blocks stay in torch's cache: the second run does not pay hipMalloc again)
         dec_s, st = min(runs, key=lambda r: r[0])
         out["decode"] = {"reads_per_s": cfg.n_reads / dec_s, "where": "gpu", "host_threads": st["threads"],
                          "GB_per_s_compressed": size / dec_s / 1e9, "GB_per_s_inflated": st["uncompressed_bytes"] / dec_s / 1e9,

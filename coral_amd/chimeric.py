@@ -33,11 +33,24 @@ class ChimericTable:
         for k in ("qs", "qe", "tid", "ra", "rb", "strand", "mapq", "cni0", "cni1", "read"):
             setattr(self, k, np.zeros(0, np.int64))
         self.nm = np.zeros(0, np.float64)
-        self.read_length = np.zeros(0, np.int64)      # per name id, -1 = no primary seen
+        self._read_length = np.zeros(0, np.int64)     # per name id, -1 = no primary seen (a device tensor until somebody asks)
         self.pairs = np.zeros((0, 8), np.int32)       # coral_bp_pair_table: two slots per row (see csrc/coral_kernels.hip, K4)
         self.dev_rows = None                          # coral_sa_table's rows as they stay in HBM (int32 [n_rows, 8])
         self.staging = None                           # owner of the pinned host buffers the arrays above are views of
         self.n_mapq60_plain = 0
+
+    @property
+    def read_length(self):
+        """Query length of the first primary record per name id (-1: none), as a host int64 array — fetched from the device the
+        first time it is asked for (the graph build itself never needs it)."""
+        rl = self._read_length
+        if not isinstance(rl, np.ndarray):
+            rl = self._read_length = rl.to("cpu").numpy().astype(np.int64)
+        return rl
+
+    @read_length.setter
+    def read_length(self, v):
+        self._read_length = v
 
     @property
     def n_reads(self):

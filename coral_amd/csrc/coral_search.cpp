@@ -1130,30 +1130,51 @@ extern "C" int coral_search_within(void *h, int32_t n_int, const int64_t *int_ti
             if (w.ra <= int_end[k] && int_start[k] <= w.rb) return k;
         return -1;
     };
-    bool contigs_ok = true;
-    std::vector<int32_t> fi;
-    std::vector<char> &used = S.main_scratch.used;
-    for (int64_t r = 0; r < S.n_reads; ++r) {
-        const int32_t *rec = rec_of(S, r);
-        const int64_t n = rec[0], base = rec[1];
-        if (n < 2) continue;
-        const PackedRow *w = rows_of(rec);
-        fi.resize((size_t)n);
-        for (int64_t k = 0; k < n; ++k) fi[(size_t)k] = first_interval(w[k]);
-        used.assign((size_t)n, 0);
-        for (int64_t k = 0; k + 1 < n; ++k) {
-            const int32_t bits = w[k].bits_adj;
-            if (!(bits & 2) || fi[(size_t)k] < 0 || fi[(size_t)k] != fi[(size_t)k + 1]) continue;
-            if ((bits & 32) || (bits & 64)) {
-                used[(size_t)k] = 1;
-                contigs_ok &= emit_adj(S, R.cand, w[k], k, r);
+    // reads in table (= dict) order; big tables are cut into consecutive ranges of reads filtered on the handle's task pool, each
+    // into a list of its own, appended in range order
+    auto scan_reads = [&](int64_t r0, int64_t r1, std::vector<int64_t> &out) {
+        bool ok = true;
+        std::vector<int32_t> fi;
+        std::vector<char> used;
+        for (int64_t r = r0; r < r1; ++r) {
+            const int32_t *rec = rec_of(S, r);
+            const int64_t n = rec[0], base = rec[1];
+            if (n < 2) continue;
+            const PackedRow *w = rows_of(rec);
+            fi.resize((size_t)n);
+            for (int64_t k = 0; k < n; ++k) fi[(size_t)k] = first_interval(w[k]);
+            used.assign((size_t)n, 0);
+            for (int64_t k = 0; k + 1 < n; ++k) {
+                const int32_t bits = w[k].bits_adj;
+                if (!(bits & 2) || fi[(size_t)k] < 0 || fi[(size_t)k] != fi[(size_t)k + 1]) continue;
+                if ((bits & 32) || (bits & 64)) {
+                    used[(size_t)k] = 1;
+                    ok &= emit_adj(S, out, w[k], k, r);
+                }
+            }
+            for (int64_t k = 1; k + 1 < n; ++k) {
+                if (used[(size_t)k - 1] || used[(size_t)k]) continue;
+                const int32_t bits = w[k].bits_skip;
+                if (!(bits & 2) || fi[(size_t)k - 1] < 0 || fi[(size_t)k - 1] != fi[(size_t)k + 1]) continue;
+                if ((bits & 32) || (bits & 64)) ok &= emit(S, out, 2 * (base + k) + 1, r, base);
             }
         }
-        for (int64_t k = 1; k + 1 < n; ++k) {
-            if (used[(size_t)k - 1] || used[(size_t)k]) continue;
-            const int32_t bits = w[k].bits_skip;
-            if (!(bits & 2) || fi[(size_t)k - 1] < 0 || fi[(size_t)k - 1] != fi[(size_t)k + 1]) continue;
-            if ((bits & 32) || (bits & 64)) contigs_ok &= emit(S, R.cand, 2 * (base + k) + 1, r, base);
+        return ok;
+    };
+    bool contigs_ok = true;
+    const int pieces = (S.pool && S.n_reads >= 4 * S.par_min_reads) ? 4 : 1;
+    if (pieces == 1) {
+        contigs_ok = scan_reads(0, S.n_reads, R.cand);
+    } else {
+        std::vector<std::vector<int64_t>> part((size_t)pieces);
+        std::vector<char> okv((size_t)pieces, 1);
+        std::vector<std::function<void()>> tasks;
+        for (int c = 0; c < pieces; ++c)
+            tasks.emplace_back([&, c]() { okv[(size_t)c] = scan_reads(S.n_reads * c / pieces, S.n_reads * (c + 1) / pieces, part[(size_t)c]); });
+        S.pool->run(tasks);
+        for (int c = 0; c < pieces; ++c) {
+            contigs_ok &= okv[(size_t)c] != 0;
+            R.cand.insert(R.cand.end(), part[(size_t)c].begin(), part[(size_t)c].end());
         }
     }
     const int64_t g[4] = {-1, -1, -1, (int64_t)(R.cand.size() / 13)};

@@ -463,10 +463,9 @@ class bam_to_breakpoint_nanopore():
         mean = s0 / T.n_mapq60_plain
         self.nm_stats = [mean, math.sqrt(s1 / T.n_mapq60_plain - mean ** 2), T.n_mapq60_plain]
         names = self.rec.names
-        has = np.nonzero(T.read_length >= 0)[0]
         # (T's host arrays are views of pinned staging buffers leased for T's lifetime: whatever outlives this object and still
         # looks at one of them holds the staging too, or the buffer would go back to the pool under it)
-        self.read_length = _LazyReadLength(names, T.read_length, has, keep=T.staging)
+        self.read_length = _LazyReadLength(names, T)
         self.chimeric_alignments = _ChimericAlignments(self, T.name_id, keep=T.staging)
         logging.info(_t() + "Fetched %d chimeric reads." % (len(self.chimeric_alignments)))
         logging.info(_t() + "Computed alignment intervals on all chimeric reads.")
@@ -1501,21 +1500,27 @@ class _LazyIndelAlignments(dict):
 
 
 class _LazyReadLength(dict):
-    """``read name -> query length`` for reads with a primary record; built from arrays on first use."""
+    """``read name -> query length`` for reads with a primary record (ibg:141-143); built from the chimeric table's per-name
+    array — which stays on the device until then — on first use."""
 
-    def __init__(self, names, rl, has, keep=None):
+    def __init__(self, names, table):
         super().__init__()
-        self._names, self._rl, self._has, self._done = names, rl, has, False
-        self._keep = keep                       # owner of the memory `rl` is a view of
+        self._names, self._table, self._done, self._has = names, table, False, None
+
+    def _which(self):
+        if self._has is None:
+            self._has = np.nonzero(self._table.read_length >= 0)[0]
+        return self._has
 
     def _fill(self):
         if not self._done:
             self._done = True
-            names, rl = self._names, self._rl
-            dict.update(self, zip(names.take(self._has), rl[self._has].tolist()))
+            has = self._which()
+            dict.update(self, zip(self._names.take(has), self._table.read_length[has].tolist()))
+            self._table = None
 
     def __len__(self):
-        return len(self._has)
+        return dict.__len__(self) if self._done else len(self._which())
 
     def __contains__(self, k):
         self._fill()
@@ -1525,6 +1530,10 @@ class _LazyReadLength(dict):
         self._fill()
         return dict.__getitem__(self, k)
 
+    def get(self, k, default=None):
+        self._fill()
+        return dict.get(self, k, default)
+
     def __iter__(self):
         self._fill()
         return dict.__iter__(self)
@@ -1533,9 +1542,34 @@ class _LazyReadLength(dict):
         self._fill()
         return dict.keys(self)
 
+    def values(self):
+        self._fill()
+        return dict.values(self)
+
     def items(self):
         self._fill()
         return dict.items(self)
+
+    def __eq__(self, other):
+        self._fill()
+        return dict.__eq__(self, other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        self._fill()
+        return dict.__repr__(self)
+
+    def copy(self):
+        self._fill()
+        return dict(self)
+
+    def __reduce__(self):
+        self._fill()
+        return (dict, (list(dict.items(self)),))
 
 
 class _SegIndexView:

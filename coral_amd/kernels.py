@@ -67,7 +67,29 @@ def _scan_local(dr, min_gap: int, min_mapq: int, gap_cap: int):
 
     state = [launch(gap_cap), gap_cap]
 
+    def staged_copy():
+        """Right behind the kernel, without waiting for it: the whole gap-row buffer, the first / last block of every row's
+        record and the counter go to pinned host memory on the copy stream — by the time the host logic asks for the rows
+        (find_smalldel_breakpoints, after the interval search) they have long landed."""
+        (gaps, cnt), cap = state
+        if dev.type != "cuda" or n == 0:
+            return None
+        idx = gaps[:, 0].clamp(0, n - 1).to(torch.int64)              # (rows beyond the count hold garbage: clamped, never read)
+        extra = summary[:n][idx][:, 2:4].contiguous()
+        st = Staged(dr)
+        return st, st.start("gaps", dict(gaps=gaps, extra=extra, cnt=cnt))
+    early = staged_copy() if dr.world == 1 else None
+
     def rows():
+        if early is not None:
+            st, h = early
+            st.wait("gaps")
+            k = int(h["cnt"][0]) & 0xFFFFFFFF
+            if k <= state[1]:
+                g = np.concatenate([h["gaps"][:k].astype(np.int64), h["extra"][:k].astype(np.int64)], axis=1) if k else np.zeros((0, 6), dtype=np.int64)
+                st.close()
+                return torch.from_numpy(g)
+            st.close()
         while True:
             (gaps, cnt), cap = state
             k = int(cnt[0].item()) & 0xFFFFFFFF
@@ -89,7 +111,8 @@ def cigar_scan(dr, min_gap: int = 600, min_mapq: int = 20, gap_cap: int = 1 << 1
 
     def gather():
         rows = pending()
-        rows[:, 0] += dr.lo
+        if dr.lo:
+            rows[:, 0] += dr.lo
         if dr.world > 1:
             rows = sharding.allgather_rows(dr, rows)
         g = rows.cpu().numpy()
@@ -334,7 +357,7 @@ class Staged:
 def _sa_table_local(dr):
     """coral_sa_table (K3) + coral_bp_pair_table (K4) on this process's GPU over ALL records' SA rows (they are tiny next to
     the CIGARs; the table is consumed by the host logic, so it is built where that runs).  Returns
-    (cols int64[8, n_rows], off int64[n_reads + 1], name_id, failed, read_length, pairs int32[2 * n_rows, 8], device rows,
+    (cols int64[8, n_rows], off int64[n_reads + 1], name_id, failed, read_length (device int32, or a host array), pairs int32[2 * n_rows, 8], device rows,
     staging): the host arrays live in ``staging``'s pinned buffers; everything but ``pairs`` has landed on return, ``pairs``
     after ``staging.wait("pairs")``."""
     d = dr.sa_device_arrays()
@@ -395,14 +418,15 @@ def _sa_table_on_current_stream(dr, d):
     # and cutting them out of a row-major [n, 8] array costs more than the whole kernel
     st = Staged(dr)
     h = st.start("table", dict(cols=out_rows[:n_rows].t().contiguous().to(torch.int64), off=out_off[:n_reads + 1].to(torch.int64),
-                               name=out_name[:n_reads].to(torch.int64), failed=out_failed[:n_reads].to(torch.bool),
-                               rl=out_rl[:dr.n_names].to(torch.int64)))
+                               name=out_name[:n_reads].to(torch.int64), failed=out_failed[:n_reads].to(torch.bool)))
     lap("staged copy: table")
     hp = st.start("pairs", dict(pairs=pairs[:2 * n_rows]))
     lap("staged copy: pairs")
     st.wait("table")
     lap("wait for the table")
-    return h["cols"], h["off"], h["name"], h["failed"], h["rl"], hp["pairs"], out_rows[:n_rows], st
+    # read_length per name id (2 M entries at config 3) stays on the device: the build never looks at it — it backs the lazily
+    # filled `read_length` dict of the object surface (ibg:141-143) and is fetched when somebody reads that dict
+    return h["cols"], h["off"], h["name"], h["failed"], out_rl[:dr.n_names], hp["pairs"], out_rows[:n_rows], st
 
 
 def pair_table(dr, off: torch.Tensor, rows: torch.Tensor, n_reads: int, n_rows: int, cutoff=100, min_mapq=20, gap_=100,

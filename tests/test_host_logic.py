@@ -31,7 +31,8 @@ def test_strict_order_in_seeded_subprocess():
 def test_strict_order_with_lookahead_threads_in_seeded_subprocess():
     """Same strict comparison with the look-ahead threads of the native interval search forced on (they are skipped for data
     sets this small by default): steps computed ahead on worker threads must not change a single byte or order."""
-    env = dict(os.environ, PYTHONHASHSEED="0", CORAL_SEARCH_MIN_READS="0", CORAL_SEARCH_THREADS="3")
+    env = dict(os.environ, PYTHONHASHSEED="0", CORAL_SEARCH_MIN_READS="0", CORAL_SEARCH_THREADS="3",
+               CORAL_SEARCH_PAR_MIN="1")          # + every step, and the whole-table pair filter, cut into task-pool chunks
     env.pop("CORAL_VERIFY_SET_ORDER", None)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider",
