@@ -68,3 +68,12 @@ def test_shard_merge_equals_reference(case, world, golden_dir, tmp_path):
     for k in res["files"]:
         compare_graph_text(res["files"][k], gold["files"][k])
         assert open(str(tmp_path / ("sh" + k[3:]))).read() == res["files"][k]
+
+
+@pytest.mark.gpu
+def test_rccl_arms_at_world_one():
+    """The RCCL arms of the exchange helpers (device tensors, backend "nccl") run — in the only RCCL world one GPU can form."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_world1.py")], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl world-1 ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
