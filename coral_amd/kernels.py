@@ -387,6 +387,7 @@ def _sa_table_on_current_stream(dr, d):
     L = _lib.lib()
     dev = dr.device
     n_sa = dr.n_sa
+    lap("enter")
     ws_bytes = max(1 << 20, 104 * max(n_sa, 1) + 8 * dr.n_names + (8 << 20))
     out_rows = torch.empty((max(n_sa, 1), 8), dtype=torch.int32, device=dev)
     out_off = torch.empty(max(n_sa, 1) + 1, dtype=torch.int32, device=dev)
@@ -394,6 +395,7 @@ def _sa_table_on_current_stream(dr, d):
     out_failed = torch.empty(max(n_sa, 1), dtype=torch.int32, device=dev)
     out_rl = torch.empty(max(dr.n_names, 1), dtype=torch.int32, device=dev)
     counts = (C.c_int32 * 2)()
+    lap("output tensors")
     while True:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         rc = L.coral_sa_table(dr.n_total, d["tid"].data_ptr(), d["flagmq"].data_ptr(), d["qlen"].data_ptr(), d["name"].data_ptr(),

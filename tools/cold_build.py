@@ -48,7 +48,7 @@ if os.environ.get("PRE_POOLS"):
 
 def one(dr, tag, profile=False):
     torch.cuda.synchronize()
-    os.environ["CORAL_TRACE_OPEN"] = "1" if "fresh" in tag else "0"
+    os.environ["CORAL_TRACE_OPEN"] = "1"
     pr = cProfile.Profile() if profile else None
     t0 = time.perf_counter()
     if pr:
