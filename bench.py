@@ -164,7 +164,14 @@ def main():
         tt = torch.tensor([h2d_ms], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         h2d_ms = float(tt.item())
-    legs = bam_legs(a, rank, world, dev, work, rec) if (a.bam_reads >= 0 and a.mode == "shard") else None
+    legs = None
+    if a.bam_reads >= 0 and a.mode == "shard":
+        try:
+            legs = bam_legs(a, rank, world, dev, work, rec, cfg.n_reads)
+        except Exception as exc:                      # noqa: BLE001 — the headline above must not be lost to a full disk or the like
+            if world > 1:
+                raise                                 # (ranks are inside collectives: no partial result there)
+            legs = {"bam_legs_error": "%s: %s" % (type(exc).__name__, exc)}
     rec = None
     b = b_last
 
@@ -296,7 +303,7 @@ def measure_h2d(dr):
     return total_ms
 
 
-def bam_legs(a, rank, world, dev, work, rec=None):
+def bam_legs(a, rank, world, dev, work, rec=None, rec_reads=0):
     """`decode`, `decode_host` and `end_to_end` on a real BAM FILE of the whole workload (default: the configuration's own read
     count — 2 M reads, 18.7 GB at config 3, the size the metric is quoted on).  Rank 0 writes the file (``rec``: the records the
     timed steps ran on, when the sizes agree) and times the whole-file decodes; then EVERY rank decodes only its byte range of it,
@@ -308,14 +315,23 @@ def bam_legs(a, rank, world, dev, work, rec=None):
     if a.reads:
         full.n_reads = a.reads
     n_bam = full.n_reads if a.bam_reads == 0 else min(a.bam_reads, full.n_reads)
+    tmp_root = os.environ.get("CORAL_BENCH_TMP", "/tmp")
+    # the file needs ~0.47 byte per read base (18.7 GB at config 3): shrink the read count to what the scratch disk holds,
+    # with room to spare, and say so in the line (never the case on the boxes seen so far)
+    need = lambda n: int(0.47 * n * full.mean_len * 1.25) + (1 << 30)
+    free = shutil.disk_usage(tmp_root).free
+    capped = False
+    while n_bam > 50000 and need(n_bam) > free:
+        n_bam //= 2
+        capped = True
     cfg = synth.scaled_config(a.config, n_bam)
-    shared = os.path.join(os.environ.get("CORAL_BENCH_TMP", "/tmp"), "coral_bench_bam_%s" % os.environ.get("MASTER_PORT", str(os.getpid())))
+    shared = os.path.join(tmp_root, "coral_bench_bam_%s" % os.environ.get("MASTER_PORT", str(os.getpid())))
     path = os.path.join(shared, "input.bam")
     cn, seeds = os.path.join(shared, "cn.bed"), os.path.join(shared, "seeds.bed")
     out = {}
     if rank == 0:
         os.makedirs(shared, exist_ok=True)
-        if rec is None or rec.n_names != cfg.n_reads:
+        if rec is None or rec_reads != cfg.n_reads:
             rec = synth.generate(cfg, dev, chunk_pieces=200000)
         synth.write_cn_bed(cfg, cn)
         synth.write_seed_bed(cfg, seeds)
@@ -347,6 +363,7 @@ def bam_legs(a, rank, world, dev, work, rec=None):
                                                                          "waited_for_gpu_seconds", "host_seconds")},
                          # the file was written seconds ago: the decoder reads it from the page cache, not from the disk
                          "file_in_page_cache": True, "n_reads": cfg.n_reads, "n_records": n_records,
+                         "capped_by_free_disk_space": capped,
                          "bam": "%d reads (%d records) of %s, %.2f GB BGZF (zlib level 1), written in %.1f s; one process, whole file" % (
                              cfg.n_reads, n_records, a.config, size / 1e9, write_s)}
         # the host pipeline (coral_bam_decode_*: zlib inflate on all host threads this process may use): the first tenth of the

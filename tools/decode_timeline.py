@@ -2,7 +2,7 @@
 
     python tools/decode_timeline.py <dir with *_kernel_trace.csv> [out.md]
 
-Groups the kernels into decode runs (a run = a maximal sequence of k_bgzf_inflate launches less than 0.5 s apart), and for every
+Groups the kernels into decode runs (a run = a maximal sequence of k_bgzf_inflate launches less than 50 ms apart), and for every
 run reports: wall span, the union of all kernel intervals (GPU busy), the union of the inflate kernels alone, time with NO kernel
 running (bubbles), per-kernel totals, and the largest gaps with the kernels on either side of them."""
 import csv
@@ -19,7 +19,7 @@ rows.sort()
 infl = [r for r in rows if "k_bgzf_inflate" in r[2]]
 runs, cur = [], []
 for r in infl:
-    if cur and r[0] - cur[-1][1] > 5e8:
+    if cur and r[0] - cur[-1][1] > 5e7:
         runs.append(cur)
         cur = []
     cur.append(r)
