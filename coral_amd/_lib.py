@@ -92,6 +92,8 @@ def lib():
     L.coral_reach_keys.restype = C.c_int
     L.coral_concordant_counts.argtypes = [C.c_int32, P, P, P, C.c_int64, P, C.c_int64, C.c_int64, P, P, P]
     L.coral_concordant_counts.restype = C.c_int
+    L.coral_independent_rows.argtypes = [C.c_int32, C.c_int32, P, P, C.c_double]
+    L.coral_independent_rows.restype = C.c_int
     L.coral_cn_solve.argtypes = [C.c_int32, C.c_int32, P, P, P, P, C.c_int32, P, P, C.POINTER(C.c_int32)]
     L.coral_cn_solve.restype = C.c_int
     L.coral_cluster_first_fit.argtypes = [C.c_int64, P, P, C.c_int64, P, C.POINTER(C.c_int32)]

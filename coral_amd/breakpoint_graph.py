@@ -333,6 +333,13 @@ def _independent_rows(A, tol=1e-9):
     m, n = A.shape
     if m == 0:
         return []
+    if os.environ.get("CORAL_CN_SOLVER", "native") != "python":          # the same selection in libcoral_hip (coral_independent_rows)
+        from . import _lib
+        Ad = np.ascontiguousarray(A, dtype=np.float64)
+        keep = np.zeros(m, dtype=np.uint8)
+        if _lib.lib().coral_independent_rows(m, n, Ad.ctypes.data, keep.ctypes.data, float(tol)) < 0:
+            raise _lib.CoralHipError("coral_independent_rows: bad arguments")
+        return np.nonzero(keep)[0].tolist()
     Q = np.zeros((min(m, n), n))
     keep = []
     for i in range(m):

@@ -494,3 +494,47 @@ extern "C" int coral_cn_solve(int32_t n, int32_t p, const double *w_inv, const d
     if (n_iter) *n_iter = it;
     return CORAL_OK;
 }
+
+
+// coral_independent_rows — a maximal linearly independent subset of the rows of A (double[m][n], entries 0 / ±1: the balance rows of
+// the CN program, bg:526-541): rows are taken in order and kept when they are not in the span of the rows kept so far (Gram-Schmidt
+// against an orthonormal basis of that span, re-orthogonalised once).  keep[m] receives 1 / 0; returns the number kept.
+extern "C" int coral_independent_rows(int32_t m, int32_t n, const double *A, uint8_t *keep, double tol) {
+    if (m < 0 || n <= 0 || (m > 0 && (!A || !keep))) return CORAL_ERR_ARG;
+    std::vector<double> Q;                       // kept rows, orthonormalised, row-major
+    std::vector<double> v((size_t)n), c;
+    int32_t k = 0;
+    const int32_t cap = m < n ? m : n;
+    for (int32_t i = 0; i < m; ++i) {
+        keep[i] = 0;
+        if (k == cap) continue;
+        double norm2 = 0.0;
+        for (int32_t j = 0; j < n; ++j) { v[(size_t)j] = A[(size_t)i * n + j]; norm2 += v[(size_t)j] * v[(size_t)j]; }
+        const double norm = sqrt(norm2);
+        if (norm == 0.0) continue;
+        for (int pass = 0; pass < 2 && k > 0; ++pass) {
+            c.assign((size_t)k, 0.0);
+            for (int32_t q = 0; q < k; ++q) {
+                double d = 0.0;
+                const double *qr = &Q[(size_t)q * n];
+                for (int32_t j = 0; j < n; ++j) d += qr[j] * v[(size_t)j];
+                c[(size_t)q] = d;
+            }
+            for (int32_t q = 0; q < k; ++q) {
+                const double *qr = &Q[(size_t)q * n];
+                const double d = c[(size_t)q];
+                for (int32_t j = 0; j < n; ++j) v[(size_t)j] -= d * qr[j];
+            }
+        }
+        double res2 = 0.0;
+        for (int32_t j = 0; j < n; ++j) res2 += v[(size_t)j] * v[(size_t)j];
+        const double res = sqrt(res2);
+        if (res > tol * (norm > 1.0 ? norm : 1.0) && res > 1e-7 * norm) {
+            Q.resize((size_t)(k + 1) * n);
+            for (int32_t j = 0; j < n; ++j) Q[(size_t)k * n + j] = v[(size_t)j] / res;
+            keep[i] = 1;
+            ++k;
+        }
+    }
+    return k;
+}

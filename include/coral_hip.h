@@ -317,6 +317,12 @@ int coral_concordant_counts(int32_t n_edges, const int64_t *pt_begin, const int6
                             const int32_t *rec_name, int64_t n_rec, int64_t n_names, const int64_t *sup_off, const int64_t *sup_name,
                             int64_t *count);
 
+/* coral_independent_rows — HOST function: keep[i] = 1 for a maximal linearly independent subset of the rows of A (double[m][n],
+ * taken in order; a row is kept when it is not in the span of the rows kept before it — Gram-Schmidt, re-orthogonalised once,
+ * residual > tol * max(1, |row|)).  The redundant balance rows of the CN program (bg:526-541) are dropped with it before
+ * coral_cn_solve.  Returns the number of rows kept, negative = bad arguments. */
+int coral_independent_rows(int32_t m, int32_t n, const double *A, uint8_t *keep, double tol);
+
 /* coral_cn_solve — HOST function: the CN assignment of one amplicon graph,  argmin Σ w_inv/x + w_lin·x − w_log·log x  s.t.
  * A x = 0, x > 0,  started at x = 1 — the convex program compute_cn_lr gives to cvxopt.solvers.cp
  * (/root/reference/src/breakpoint_graph.py:495-606; one variable per edge, one balance row per interior node).  A double[p][n]

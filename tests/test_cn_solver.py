@@ -67,3 +67,18 @@ def test_native_solver_reports_a_singular_system_instead_of_guessing():
                                    nu.ctypes.data, C.byref(it))
     assert rc == 1
     assert _lib.lib().coral_cn_solve(0, 0, None, None, None, None, 10, None, None, None) < 0
+
+
+def test_native_row_selection_equals_the_numpy_one(monkeypatch):
+    rng = np.random.default_rng(3)
+    for trial in range(40):
+        w = _problem(rng, int(rng.integers(2, 30)))
+        A = w[3]
+        extra = [A[int(rng.integers(0, len(A)))] for _ in range(int(rng.integers(0, 4)))]          # duplicated rows
+        extra += [A[0] + A[1]] if len(A) > 1 else []                                               # a dependent combination
+        B = np.vstack([A] + extra) if extra else A
+        B = B[rng.permutation(len(B))]
+        monkeypatch.setenv("CORAL_CN_SOLVER", "python")
+        want = bg._independent_rows(B)
+        monkeypatch.setenv("CORAL_CN_SOLVER", "native")
+        assert bg._independent_rows(B) == want and len(want) == np.linalg.matrix_rank(B)
