@@ -24,6 +24,10 @@ import os
 # get the process throttled); set before numpy / torch are imported
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
     os.environ.setdefault(_v, "1" if _v.startswith("OPENBLAS") else "4")
+# hardware queues per device: ROCm's default is 4, and streams beyond that share queues — the decoder's three streams, the build's
+# side streams and torch's own then serialise work that is meant to overlap (measured: the full-file decode 2.5 s instead of 1.9 s in
+# this process).  Must be set before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import shutil
 import sys
 import tempfile

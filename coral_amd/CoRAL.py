@@ -16,6 +16,7 @@ import sys
 # host side = one thread + a few native workers: keep the per-core OpenMP / BLAS pools from spinning (coral_amd/hostpools.py)
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
     os.environ.setdefault(_v, "1" if _v.startswith("OPENBLAS") else "4")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # (ROCm's default of 4 hardware queues makes the decoder's and the build's streams share queues)
 
 
 def print_args(args_dict):
