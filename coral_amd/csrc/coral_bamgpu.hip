@@ -206,6 +206,177 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
         }
         a += len;
     }
+    // The hot path of the symbol loop, by hand (gfx950 ISA).  The compiler turns Inflater::codes_vector into a state machine of
+    // boolean SGPR pairs and register copies at every join (≈42 scalar + 13 branch instructions per symbol, and the CU's one
+    // scalar pipe is what bounds the kernel); this loop spends ≈13 scalar instructions on a literal and ≈30 on a match.  It takes
+    // what is common — literal / length / distance codes found in the LDS tables, refills from the current input register,
+    // matches of at most 64 bytes whose source is still in the ring — and RETURNS, with nothing half-done, where it cannot go on:
+    //   0  at a symbol boundary: `a` reached `lim` (a line of output is complete, or the block's last 66 bytes begin, or fail()
+    //      asked for a stop), the refill would switch the input register, or the code is not in the table (long code, end of block)
+    //   1  a length has been read (lenv) and the input register must be switched, or the distance code is not in the table
+    //   2  length and distance have been read (lenv, distv), but the match is longer than 64 bytes, or reaches behind the ring /
+    //      in front of the block (`dlim` is taken at entry: a distance the general path accepts may come back here, never the
+    //      other way round)
+    // and Inflater::codes_vector does that one step.  Everything is wave-uniform; the lanes only differ in the copy.  The bit
+    // buffer lives in s[70:71] inside (its low half is needed on its own), s[72:73] hold a refill.
+    // Hazards of gfx940-class hardware that the assembler does not pad inside inline assembly: a VALU result read by
+    // v_readfirstlane needs one wait state, a transcendental result (v_rcp_f32) read by another VALU instruction one.
+    static constexpr bool has_fast = (ABLATE == 0);
+    __device__ __forceinline__ int fast(uint64_t &bb, int &bc, long long &dwords, const coral_inflate::Tables *T, uint32_t &lenv, uint32_t &distv) {
+        const int lim = attend < aend - 66 ? attend : aend - 66;
+        const uint32_t span = (uint32_t)(a - a0);
+        const uint32_t dlim = span < (uint32_t)(RING_BYTES - 64) ? span : (uint32_t)(RING_BYTES - 64);
+        const uint32_t ring_lds = (uint32_t)(uintptr_t)ring, ll_lds = (uint32_t)(uintptr_t)T->ll, dt_lds = (uint32_t)(uintptr_t)T->dt;
+        int state, nref;
+        uint32_t se, sn, st, sx, slen;
+        uint32_t vb, ve, vt, vn, vxb, vx, vd, vq, vs, vw, out_len, out_dist;
+        asm volatile(
+            "s_mov_b64 s[70:71], %[bb]\n"
+            "s_mov_b32 %[nref], 0\n"
+            "s_mov_b32 %[slen], 0\n"
+            "v_mov_b32 %[odist], 0\n"
+            "Ltop_%=:\n"
+            "s_cmp_ge_i32 %[a], %[lim]\n"
+            "s_cbranch_scc1 Lexit0_%=\n"
+            "s_cmp_gt_i32 %[bc], 32\n"
+            "s_cbranch_scc1 Lsym_%=\n"
+            "s_cmp_eq_u32 %[idx], 63\n"
+            "s_cbranch_scc1 Lexit0_%=\n"
+            "v_readlane_b32 s72, %[r0], %[idx]\n"
+            "s_mov_b32 s73, 0\n"
+            "s_lshl_b64 s[72:73], s[72:73], %[bc]\n"
+            "s_or_b64 s[70:71], s[70:71], s[72:73]\n"
+            "s_add_i32 %[bc], %[bc], 32\n"
+            "s_add_i32 %[idx], %[idx], 1\n"
+            "s_add_i32 %[nref], %[nref], 1\n"
+            "Lsym_%=:\n"                                       // more than 32 bits: first table look-up of the round
+            "v_mov_b32 %[vb], s70\n"
+            "v_and_b32 %[vt], 0x3ff, %[vb]\n"
+            "v_lshl_add_u32 %[vt], %[vt], 1, %[llb]\n"
+            "ds_read_u16 %[ve], %[vt]\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "v_readfirstlane_b32 %[se], %[ve]\n"
+            "s_bitcmp1_b32 %[se], 4\n"
+            "s_cbranch_scc1 Lnotlit_%=\n"
+            "s_and_b32 %[sn], %[se], 15\n"                     // literal
+            "s_lshr_b64 s[70:71], s[70:71], %[sn]\n"
+            "s_sub_i32 %[bc], %[bc], %[sn]\n"
+            "v_lshrrev_b32 %[vx], 8, %[ve]\n"
+            "s_and_b32 %[st], %[a], %[mask]\n"
+            "s_add_i32 %[st], %[st], %[ring]\n"
+            "v_mov_b32 %[vt], %[st]\n"
+            "ds_write_b8 %[vt], %[vx]\n"
+            "s_add_i32 %[a], %[a], 1\n"
+            "v_mov_b32 %[vb], s70\n"                           // at least 23 bits left: second look-up without a refill check
+            "v_and_b32 %[vt], 0x3ff, %[vb]\n"
+            "v_lshl_add_u32 %[vt], %[vt], 1, %[llb]\n"
+            "ds_read_u16 %[ve], %[vt]\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "v_readfirstlane_b32 %[se], %[ve]\n"
+            "s_bitcmp1_b32 %[se], 4\n"
+            "s_cbranch_scc1 Lnotlit_%=\n"
+            "s_and_b32 %[sn], %[se], 15\n"                     // second literal
+            "s_lshr_b64 s[70:71], s[70:71], %[sn]\n"
+            "s_sub_i32 %[bc], %[bc], %[sn]\n"
+            "v_lshrrev_b32 %[vx], 8, %[ve]\n"
+            "s_and_b32 %[st], %[a], %[mask]\n"
+            "s_add_i32 %[st], %[st], %[ring]\n"
+            "v_mov_b32 %[vt], %[st]\n"
+            "ds_write_b8 %[vt], %[vx]\n"
+            "s_add_i32 %[a], %[a], 1\n"
+            "s_branch Ltop_%=\n"
+            "Lnotlit_%=:\n"                                    // se = table entry, s70 = the bits it was looked up with (>= 23)
+            "s_and_b32 %[sn], %[se], 15\n"
+            "s_cmp_eq_u32 %[sn], 0\n"
+            "s_cbranch_scc1 Lexit0_%=\n"                       // not in the table
+            "s_bfe_u32 %[sx], %[se], 0x30005\n"                // extra bits of the length code
+            "s_lshr_b32 %[slen], %[se], 8\n"                   // length base - 3
+            "s_lshr_b32 %[st], s70, %[sn]\n"
+            "s_bfm_b32 s72, %[sx], 0\n"
+            "s_and_b32 %[st], %[st], s72\n"
+            "s_add_i32 %[slen], %[slen], %[st]\n"
+            "s_add_i32 %[slen], %[slen], 3\n"
+            "s_add_i32 %[sn], %[sn], %[sx]\n"
+            "s_lshr_b64 s[70:71], s[70:71], %[sn]\n"
+            "s_sub_i32 %[bc], %[bc], %[sn]\n"
+            "s_cmp_gt_i32 %[bc], 32\n"                         // the distance code needs up to 8 + 13 bits
+            "s_cbranch_scc1 Ldist_%=\n"
+            "s_cmp_eq_u32 %[idx], 63\n"
+            "s_cbranch_scc1 Lexit1_%=\n"
+            "v_readlane_b32 s72, %[r0], %[idx]\n"
+            "s_mov_b32 s73, 0\n"
+            "s_lshl_b64 s[72:73], s[72:73], %[bc]\n"
+            "s_or_b64 s[70:71], s[70:71], s[72:73]\n"
+            "s_add_i32 %[bc], %[bc], 32\n"
+            "s_add_i32 %[idx], %[idx], 1\n"
+            "s_add_i32 %[nref], %[nref], 1\n"
+            "Ldist_%=:\n"
+            "v_mov_b32 %[vb], s70\n"
+            "v_and_b32 %[vt], 0xff, %[vb]\n"
+            "v_lshl_add_u32 %[vt], %[vt], 2, %[dtb]\n"
+            "ds_read_b32 %[vd], %[vt]\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "v_readfirstlane_b32 %[se], %[vd]\n"
+            "v_and_b32 %[vn], 15, %[vd]\n"
+            "v_bfe_u32 %[vxb], %[vd], 8, 4\n"
+            "v_lshrrev_b32 %[vx], 16, %[vd]\n"
+            "v_bfe_u32 %[vt], %[vb], %[vn], %[vxb]\n"
+            "v_add_u32 %[odist], %[vx], %[vt]\n"
+            "s_and_b32 %[sn], %[se], 15\n"
+            "s_cmp_eq_u32 %[sn], 0\n"
+            "s_cbranch_scc1 Lexit1_%=\n"                       // distance code not in the table (nothing of it consumed)
+            "s_bfe_u32 %[sx], %[se], 0x40008\n"
+            "s_add_i32 %[sn], %[sn], %[sx]\n"
+            "s_lshr_b64 s[70:71], s[70:71], %[sn]\n"
+            "s_sub_i32 %[bc], %[bc], %[sn]\n"
+            "s_cmp_gt_u32 %[slen], 64\n"
+            "s_cbranch_scc1 Lexit2_%=\n"
+            "v_cmp_lt_u32 vcc, %[dlim], %[odist]\n"            // behind the ring, or in front of the block's first byte
+            "s_cbranch_vccnz Lexit2_%=\n"
+            "v_cvt_f32_u32 %[vq], %[odist]\n"                  // byte k of the match = byte (k mod dist) of the dist bytes in front
+            "v_rcp_f32 %[vq], %[vq]\n"
+            "v_sub_u32 %[vs], %[a], %[odist]\n"
+            "v_add_u32 %[vw], %[a], %[lane]\n"
+            "v_mul_f32 %[vq], %[laneh], %[vq]\n"               // floor((lane + 0.5) / dist): exact (DevWaveT::match)
+            "v_cvt_u32_f32 %[vq], %[vq]\n"
+            "v_mul_lo_u32 %[vq], %[vq], %[odist]\n"
+            "v_sub_u32 %[vq], %[lane], %[vq]\n"
+            "v_add_u32 %[vs], %[vs], %[vq]\n"
+            "v_and_b32 %[vs], %[mask], %[vs]\n"
+            "v_add_u32 %[vs], %[ring], %[vs]\n"
+            "v_and_b32 %[vw], %[mask], %[vw]\n"
+            "v_add_u32 %[vw], %[ring], %[vw]\n"
+            "v_cmp_gt_u32 vcc, %[slen], %[lane]\n"
+            "s_mov_b64 exec, vcc\n"
+            "ds_read_u8 %[vx], %[vs]\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "ds_write_b8 %[vw], %[vx]\n"
+            "s_mov_b64 exec, -1\n"
+            "s_add_i32 %[a], %[a], %[slen]\n"
+            "s_branch Ltop_%=\n"
+            "Lexit2_%=:\n"
+            "s_mov_b32 %[state], 2\n"
+            "s_branch Lout_%=\n"
+            "Lexit1_%=:\n"
+            "s_mov_b32 %[state], 1\n"
+            "s_branch Lout_%=\n"
+            "Lexit0_%=:\n"
+            "s_mov_b32 %[state], 0\n"
+            "Lout_%=:\n"
+            "v_mov_b32 %[olen], %[slen]\n"
+            "s_mov_b64 %[bb], s[70:71]\n"
+            : [bb] "+s"(bb), [bc] "+s"(bc), [idx] "+s"(idx), [a] "+s"(a), [state] "=&s"(state), [nref] "=&s"(nref), [se] "=&s"(se),
+              [sn] "=&s"(sn), [st] "=&s"(st), [sx] "=&s"(sx), [slen] "=&s"(slen), [vb] "=&v"(vb), [ve] "=&v"(ve), [vt] "=&v"(vt),
+              [vn] "=&v"(vn), [vxb] "=&v"(vxb), [vx] "=&v"(vx), [vd] "=&v"(vd), [vq] "=&v"(vq), [vs] "=&v"(vs), [vw] "=&v"(vw),
+              [olen] "=&v"(out_len), [odist] "=&v"(out_dist)
+            : [lim] "s"(lim), [dlim] "s"(dlim), [ring] "s"(ring_lds), [llb] "s"(ll_lds), [dtb] "s"(dt_lds), [r0] "v"(r0), [lane] "v"(lane),
+              [laneh] "v"(lane_half), [mask] "n"(RING_MASK)
+            : "s70", "s71", "s72", "s73", "vcc", "scc", "memory");
+        dwords += nref;
+        lenv = out_len;
+        distv = out_dist;
+        return state;
+    }
     __device__ __forceinline__ bool copy_match(int len, int dist) {   // (the plain loop's interface; unused on the device)
         match((uint32_t)len, (uint32_t)dist);
         return true;

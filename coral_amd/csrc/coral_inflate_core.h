@@ -312,74 +312,87 @@ struct Inflater {
     // output (`over`, looked at once per round), and the canonical loop handles codes longer than the table, unused patterns
     // and the end of the block.  Values named *v live in vector registers on the device (plain integers on the host).
     // Needs from the backend: vec(x), bfe(x, offset, width), lit(bytev), match(lenv, distv), needs_attention() / attention()
-    // (one compare per round: output to be written back, or the loop is to stop), fail(code) / failed() / error_code().
+    // (one compare per round: output to be written back, or the loop is to stop), fail(code) / failed() / error_code(), and
+    // `static constexpr bool has_fast` (+ fast(bb, bc, dwords, tables, lenv, distv) when true, see the loop).
     CORAL_HD int codes_vector() {
         const uint16_t *ll = T->ll;
         const uint32_t *dt = T->dt;
         // ONE way out besides the end-of-block code: every rare problem raises the backend's flag (fail), and the round's
         // single check sees it — several `return`s inside the loop cost a scalar state machine in every round
         for (;;) {
-            if (CORAL_UNLIKELY(w.needs_attention()) && !w.attention()) break;      // a line of output is complete, or stop
-            need();                                                   // more than 32 bits
-            uint32_t bbv = w.vec((uint32_t)bb);
-            uint32_t ev = ll[bbv & ((1u << LL_BITS) - 1u)];
-            uint32_t e = w.uni(ev);
-            if (!(e & LL_NOT_LITERAL)) {
-                const uint32_t nb1 = e & 15u;
-                bb >>= nb1;
-                bc -= (int)nb1;
-                w.lit(ev >> 8);
-                bbv = w.vec((uint32_t)bb);                            // at least 23 bits left: enough for any table entry
-                ev = ll[bbv & ((1u << LL_BITS) - 1u)];
-                e = w.uni(ev);
+            // A backend with a hand-written fast path (W::has_fast: the device, DevWaveT::fast) decodes as many symbols as it
+            // can there — table hits, short near matches, input still in the window — and comes back where it cannot go on:
+            //   0  at a symbol boundary (attention due, a code outside the tables, the input window to be switched, ...)
+            //   1  a match length has been read (lenv), its distance code is next
+            //   2  length and distance have been read (lenv, distv), the copy is not done
+            // and this loop does that ONE step the general way.  Without a fast path every round starts at 0.
+            uint32_t lenv = 0, distv = 0;
+            int at = 0;
+            if constexpr (W::has_fast) at = w.fast(bb, bc, dwords, T, lenv, distv);
+            if (at == 0) {
+                if (CORAL_UNLIKELY(w.needs_attention()) && !w.attention()) break;      // a line of output is complete, or stop
+                need();                                                   // more than 32 bits
+                uint32_t bbv = w.vec((uint32_t)bb);
+                uint32_t ev = ll[bbv & ((1u << LL_BITS) - 1u)];
+                uint32_t e = w.uni(ev);
                 if (!(e & LL_NOT_LITERAL)) {
-                    const uint32_t nb2 = e & 15u;
-                    bb >>= nb2;
-                    bc -= (int)nb2;
+                    const uint32_t nb1 = e & 15u;
+                    bb >>= nb1;
+                    bc -= (int)nb1;
                     w.lit(ev >> 8);
-                    continue;
+                    if constexpr (W::has_fast) continue;                  // (the fast path takes the literals that follow)
+                    bbv = w.vec((uint32_t)bb);                            // at least 23 bits left: enough for any table entry
+                    ev = ll[bbv & ((1u << LL_BITS) - 1u)];
+                    e = w.uni(ev);
+                    if (!(e & LL_NOT_LITERAL)) {
+                        const uint32_t nb2 = e & 15u;
+                        bb >>= nb2;
+                        bc -= (int)nb2;
+                        w.lit(ev >> 8);
+                        continue;
+                    }
+                }
+                if (CORAL_UNLIKELY((e & 15u) == 0)) {                     // not in the table: canonical decode (up to 15 of >= 23 bits)
+                    const int s = decode_long(T->ll_count, T->ll_sym);
+                    if (s == 256) return w.failed() ? w.error_code() : OK;
+                    const uint32_t x = s < 0 ? (uint32_t)LL_LONG : ll_entry((uint32_t)s, 1);     // (a length of 1 tells a length-3 code from LL_LONG)
+                    if (s >= 0 && s < 256) {
+                        w.lit((uint32_t)s);
+                        continue;
+                    }
+                    if (x == LL_LONG) {
+                        w.fail(ERR_BAD_CODE);
+                        continue;
+                    }
+                    lenv = 3u + (x >> 8) + bits((int)((x >> 5) & 7u));
+                } else {                                                  // a length: code + extra bits leave the buffer in one shift
+                    const uint32_t nbv = ev & 15u, xbv = (ev >> 5) & 7u;
+                    lenv = 3u + (ev >> 8) + w.bfe(bbv, nbv, xbv);
+                    const uint32_t tot = w.uni(nbv + xbv);                // <= 10 + 5
+                    bb >>= tot;
+                    bc -= (int)tot;
                 }
             }
-            uint32_t lenv;
-            if (CORAL_UNLIKELY((e & 15u) == 0)) {                     // not in the table: canonical decode (up to 15 of >= 23 bits)
-                const int s = decode_long(T->ll_count, T->ll_sym);
-                if (s == 256) return w.failed() ? w.error_code() : OK;
-                const uint32_t x = s < 0 ? (uint32_t)LL_LONG : ll_entry((uint32_t)s, 1);     // (a length of 1 tells a length-3 code from LL_LONG)
-                if (s >= 0 && s < 256) {
-                    w.lit((uint32_t)s);
-                    continue;
+            if (at <= 1) {
+                need();
+                const uint32_t bbv = w.vec((uint32_t)bb);
+                const uint32_t dv = dt[bbv & ((1u << D_BITS) - 1u)];
+                const uint32_t d = w.uni(dv);
+                if (CORAL_UNLIKELY((d & 15u) == 0)) {
+                    const int s = decode_long(T->d_count, T->ll_sym + 288);
+                    const uint32_t x = s < 0 ? 0u : dist_entry((uint32_t)s, 1);
+                    if (x == 0) {
+                        w.fail(ERR_BAD_CODE);
+                        continue;
+                    }
+                    distv = (x >> 16) + bits((int)((x >> 8) & 15u));
+                } else {
+                    const uint32_t nbv = dv & 15u, xbv = (dv >> 8) & 15u;
+                    distv = (dv >> 16) + w.bfe(bbv, nbv, xbv);            // <= 15 + 13 of the 32 low bits
+                    const uint32_t tot = w.uni(nbv + xbv);
+                    bb >>= tot;
+                    bc -= (int)tot;
                 }
-                if (x == LL_LONG) {
-                    w.fail(ERR_BAD_CODE);
-                    continue;
-                }
-                lenv = 3u + (x >> 8) + bits((int)((x >> 5) & 7u));
-            } else {                                                  // a length: code + extra bits leave the buffer in one shift
-                const uint32_t nbv = ev & 15u, xbv = (ev >> 5) & 7u;
-                lenv = 3u + (ev >> 8) + w.bfe(bbv, nbv, xbv);
-                const uint32_t tot = w.uni(nbv + xbv);                // <= 10 + 5
-                bb >>= tot;
-                bc -= (int)tot;
-            }
-            need();
-            bbv = w.vec((uint32_t)bb);
-            const uint32_t dv = dt[bbv & ((1u << D_BITS) - 1u)];
-            const uint32_t d = w.uni(dv);
-            uint32_t distv;
-            if (CORAL_UNLIKELY((d & 15u) == 0)) {
-                const int s = decode_long(T->d_count, T->ll_sym + 288);
-                const uint32_t x = s < 0 ? 0u : dist_entry((uint32_t)s, 1);
-                if (x == 0) {
-                    w.fail(ERR_BAD_CODE);
-                    continue;
-                }
-                distv = (x >> 16) + bits((int)((x >> 8) & 15u));
-            } else {
-                const uint32_t nbv = dv & 15u, xbv = (dv >> 8) & 15u;
-                distv = (dv >> 16) + w.bfe(bbv, nbv, xbv);            // <= 15 + 13 of the 32 low bits
-                const uint32_t tot = w.uni(nbv + xbv);
-                bb >>= tot;
-                bc -= (int)tot;
             }
             w.match(lenv, distv);
         }

@@ -7,9 +7,61 @@
 
 using namespace coral_inflate;
 
-template <bool VECTOR>
+template <bool VECTOR, bool FAST = false>
 struct HostWaveT {
     static constexpr bool vector_loop = VECTOR;
+    // FAST: a stand-in for the device backend's hand-written fast path (DevWaveT::fast in coral_bamgpu.hip) with the same
+    // contract — it decodes table-hit symbols itself and comes back in state 0 / 1 / 2 (see Inflater::codes_vector) — leaving at
+    // pseudo-random points as well, so that every way of resuming the general loop is exercised against zlib here on the host.
+    static constexpr bool has_fast = FAST;
+    uint32_t rng = 2463534242u;
+    bool coin(int one_in) {
+        rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5;
+        return rng % (uint32_t)one_in == 0;
+    }
+    int fast(uint64_t &bb, int &bc, long long &dwords, const Tables *T, uint32_t &lenv, uint32_t &distv) {
+        for (;;) {
+            if (over || coin(23)) return 0;
+            if (bc <= 32) {
+                if (coin(5)) return 0;
+                bb |= (uint64_t)next_dword() << bc;
+                bc += 32;
+                ++dwords;
+            }
+            uint32_t e = T->ll[(uint32_t)bb & ((1u << LL_BITS) - 1u)];
+            if (!(e & LL_NOT_LITERAL)) {
+                bb >>= e & 15u; bc -= (int)(e & 15u);
+                lit(e >> 8);
+                e = T->ll[(uint32_t)bb & ((1u << LL_BITS) - 1u)];
+                if (!(e & LL_NOT_LITERAL)) {
+                    bb >>= e & 15u; bc -= (int)(e & 15u);
+                    lit(e >> 8);
+                    continue;
+                }
+            }
+            if ((e & 15u) == 0) return 0;
+            {
+                const uint32_t nb = e & 15u, xb = (e >> 5) & 7u;
+                lenv = 3u + (e >> 8) + bfe((uint32_t)bb, nb, xb);
+                bb >>= nb + xb; bc -= (int)(nb + xb);
+            }
+            if (bc <= 32) {
+                if (coin(3)) return 1;
+                bb |= (uint64_t)next_dword() << bc;
+                bc += 32;
+                ++dwords;
+            }
+            const uint32_t d = T->dt[(uint32_t)bb & ((1u << D_BITS) - 1u)];
+            if ((d & 15u) == 0 || coin(11)) return 1;
+            {
+                const uint32_t nb = d & 15u, xb = (d >> 8) & 15u;
+                distv = (d >> 16) + bfe((uint32_t)bb, nb, xb);
+                bb >>= nb + xb; bc -= (int)(nb + xb);
+            }
+            if (lenv > 64u || distv > (uint32_t)o || (int)lenv > cap - o || coin(7)) return 2;
+            match(lenv, distv);
+        }
+    }
     const uint8_t *src;
     long long src_len;
     uint8_t *out;
@@ -74,19 +126,20 @@ struct HostWaveT {
     void fence() {}
 };
 
-template <bool VECTOR>
+template <bool VECTOR, bool FAST = false>
 static int run(const uint8_t *src, long long n, uint8_t *out, int cap, int *produced) {
     static Tables T;
-    HostWaveT<VECTOR> w;
+    HostWaveT<VECTOR, FAST> w;
     w.src = src; w.src_len = n; w.out = out; w.cap = cap;
-    Inflater<HostWaveT<VECTOR>> inf(w, &T);
+    Inflater<HostWaveT<VECTOR, FAST>> inf(w, &T);
     int rc = inf.run();
     if (rc == OK && w.failed()) rc = w.error_code();
     *produced = w.o;
     return rc;
 }
 
-// paired = 1: the symbol loop the device runs (Inflater::codes_vector); 0: the plain loop
+// paired = 1: the symbol loop the device runs (Inflater::codes_vector); 2: the same with a fast path in front of it that
+// comes back in every state (what the device's hand-written loop does); 0: the plain loop
 extern "C" int coral_test_inflate(const uint8_t *src, long long n, uint8_t *out, int cap, int *produced, int paired) {
-    return paired ? run<true>(src, n, out, cap, produced) : run<false>(src, n, out, cap, produced);
+    return paired == 2 ? run<true, true>(src, n, out, cap, produced) : paired ? run<true>(src, n, out, cap, produced) : run<false>(src, n, out, cap, produced);
 }
