@@ -210,20 +210,21 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
     // boolean SGPR pairs and register copies at every join (≈42 scalar + 13 branch instructions per symbol, and the CU's one
     // scalar pipe is what bounds the kernel); this loop spends ≈13 scalar instructions on a literal and ≈30 on a match.  It takes
     // what is common — literal / length / distance codes found in the LDS tables, refills from the current input register,
-    // matches of at most 64 bytes whose source is still in the ring — and RETURNS, with nothing half-done, where it cannot go on:
-    //   0  at a symbol boundary: `a` reached `lim` (a line of output is complete, or the block's last 66 bytes begin, or fail()
+    // every match whose distance is known to lie inside the block (from the ring, or from global memory once the source has left
+    // the ring) — and RETURNS, with nothing half-done, where it cannot go on:
+    //   0  at a symbol boundary: `a` reached `lim` (a line of output is complete, or the block's last 260 bytes begin, or fail()
     //      asked for a stop), the refill would switch the input register, or the code is not in the table (long code, end of block)
     //   1  a length has been read (lenv) and the input register must be switched, or the distance code is not in the table
-    //   2  length and distance have been read (lenv, distv), but the match is longer than 64 bytes, or reaches behind the ring /
-    //      in front of the block (`dlim` is taken at entry: a distance the general path accepts may come back here, never the
-    //      other way round)
+    //   2  length and distance have been read (lenv, distv), but the distance reaches further back than this call's first byte
+    //      was from the block's start (`span` is taken at entry: a distance the general path accepts may come back here, never
+    //      the other way round)
     // and Inflater::codes_vector does that one step.  Everything is wave-uniform; the lanes only differ in the copy.  The bit
     // buffer lives in s[70:71] inside (its low half is needed on its own), s[72:73] hold a refill.
     // Hazards of gfx940-class hardware that the assembler does not pad inside inline assembly: a VALU result read by
     // v_readfirstlane needs one wait state, a transcendental result (v_rcp_f32) read by another VALU instruction one.
     static constexpr bool has_fast = (ABLATE == 0);
     __device__ __forceinline__ int fast(uint64_t &bb, int &bc, long long &dwords, const coral_inflate::Tables *T, uint32_t &lenv, uint32_t &distv) {
-        const int lim = attend < aend - 66 ? attend : aend - 66;
+        const int lim = attend < aend - 260 ? attend : aend - 260;
         const uint32_t span = (uint32_t)(a - a0);
         const uint32_t dlim = span < (uint32_t)(RING_BYTES - 64) ? span : (uint32_t)(RING_BYTES - 64);
         const uint32_t ring_lds = (uint32_t)(uintptr_t)ring, ll_lds = (uint32_t)(uintptr_t)T->ll, dt_lds = (uint32_t)(uintptr_t)T->dt;
@@ -265,7 +266,9 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
             "s_and_b32 %[st], %[a], %[mask]\n"
             "s_add_i32 %[st], %[st], %[ring]\n"
             "v_mov_b32 %[vt], %[st]\n"
+            "s_mov_b64 exec, 1\n"                              // one lane writes (64 lanes storing to one address are 64 LDS accesses)
             "ds_write_b8 %[vt], %[vx]\n"
+            "s_mov_b64 exec, -1\n"
             "s_add_i32 %[a], %[a], 1\n"
             "v_mov_b32 %[vb], s70\n"                           // at least 23 bits left: second look-up without a refill check
             "v_and_b32 %[vt], 0x3ff, %[vb]\n"
@@ -282,7 +285,9 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
             "s_and_b32 %[st], %[a], %[mask]\n"
             "s_add_i32 %[st], %[st], %[ring]\n"
             "v_mov_b32 %[vt], %[st]\n"
+            "s_mov_b64 exec, 1\n"                              // one lane writes (64 lanes storing to one address are 64 LDS accesses)
             "ds_write_b8 %[vt], %[vx]\n"
+            "s_mov_b64 exec, -1\n"
             "s_add_i32 %[a], %[a], 1\n"
             "s_branch Ltop_%=\n"
             "Lnotlit_%=:\n"                                    // se = table entry, s70 = the bits it was looked up with (>= 23)
@@ -329,15 +334,15 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
             "s_add_i32 %[sn], %[sn], %[sx]\n"
             "s_lshr_b64 s[70:71], s[70:71], %[sn]\n"
             "s_sub_i32 %[bc], %[bc], %[sn]\n"
+            "v_cmp_lt_u32 vcc, %[dlim], %[odist]\n"            // behind the ring, or maybe in front of the block's first byte
+            "s_cbranch_vccnz Lfarq_%=\n"
             "s_cmp_gt_u32 %[slen], 64\n"
-            "s_cbranch_scc1 Lexit2_%=\n"
-            "v_cmp_lt_u32 vcc, %[dlim], %[odist]\n"            // behind the ring, or in front of the block's first byte
-            "s_cbranch_vccnz Lexit2_%=\n"
+            "s_cbranch_scc1 Llong_%=\n"
             "v_cvt_f32_u32 %[vq], %[odist]\n"                  // byte k of the match = byte (k mod dist) of the dist bytes in front
             "v_rcp_f32 %[vq], %[vq]\n"
             "v_sub_u32 %[vs], %[a], %[odist]\n"
             "v_add_u32 %[vw], %[a], %[lane]\n"
-            "v_mul_f32 %[vq], %[laneh], %[vq]\n"               // floor((lane + 0.5) / dist): exact (DevWaveT::match)
+            "v_mul_f32 %[vq], %[laneh], %[vq]\n"               // floor((lane + 0.5) / dist): exact (DevWaveT::match); 0 for dist >= 64
             "v_cvt_u32_f32 %[vq], %[vq]\n"
             "v_mul_lo_u32 %[vq], %[vq], %[odist]\n"
             "v_sub_u32 %[vq], %[lane], %[vq]\n"
@@ -352,6 +357,66 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
             "s_waitcnt lgkmcnt(0)\n"
             "ds_write_b8 %[vw], %[vx]\n"
             "s_mov_b64 exec, -1\n"
+            "s_add_i32 %[a], %[a], %[slen]\n"
+            "s_branch Ltop_%=\n"
+            "Llong_%=:\n"                                      // 65..258 bytes, source in the ring: chunks of 64 in order (a chunk may
+            "v_cvt_f32_u32 %[vq], %[odist]\n"                  // read what the chunk before it wrote: LDS operations of a wave execute in order)
+            "v_rcp_f32 %[vn], %[vq]\n"
+            "v_mov_b32 %[vxb], %[lane]\n"                      // k
+            "v_mov_b32 %[vd], %[laneh]\n"                      // k + 0.5
+            "s_mov_b32 %[sx], 0\n"
+            "Lchunk_%=:\n"
+            "v_mul_f32 %[vq], %[vd], %[vn]\n"
+            "v_cvt_u32_f32 %[vq], %[vq]\n"
+            "v_mul_lo_u32 %[vq], %[vq], %[odist]\n"
+            "v_sub_u32 %[vq], %[vxb], %[vq]\n"                 // k mod dist (when dist < 64)
+            "v_cmp_gt_u32 vcc, 64, %[odist]\n"
+            "v_cndmask_b32 %[vq], %[vxb], %[vq], vcc\n"        // dist >= 64: k itself
+            "v_sub_u32 %[vs], %[a], %[odist]\n"
+            "v_add_u32 %[vs], %[vs], %[vq]\n"
+            "v_and_b32 %[vs], %[mask], %[vs]\n"
+            "v_add_u32 %[vs], %[ring], %[vs]\n"
+            "v_add_u32 %[vw], %[a], %[vxb]\n"
+            "v_and_b32 %[vw], %[mask], %[vw]\n"
+            "v_add_u32 %[vw], %[ring], %[vw]\n"
+            "v_cmp_gt_u32 vcc, %[slen], %[vxb]\n"
+            "s_mov_b64 exec, vcc\n"
+            "ds_read_u8 %[vx], %[vs]\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "ds_write_b8 %[vw], %[vx]\n"
+            "s_mov_b64 exec, -1\n"
+            "v_add_u32 %[vxb], 64, %[vxb]\n"
+            "v_add_f32 %[vd], 0x42800000, %[vd]\n"             // + 64.0
+            "s_add_i32 %[sx], %[sx], 64\n"
+            "s_cmp_lt_u32 %[sx], %[slen]\n"
+            "s_cbranch_scc1 Lchunk_%=\n"
+            "s_add_i32 %[a], %[a], %[slen]\n"
+            "s_branch Ltop_%=\n"
+            "Lfarq_%=:\n"
+            "v_cmp_lt_u32 vcc, %[dspan], %[odist]\n"           // further back than this call's first output byte was from the
+            "s_cbranch_vccnz Lexit2_%=\n"                      // block's start: the general path tells a bad distance from a good one
+            // the source has left the ring (dist > RING_BYTES - 64): it is in global memory, drained up to the last 256-byte line
+            // boundary, and a - dist + len lies below that (DevWaveT::match)
+            "v_sub_u32 %[vs], %[a], %[odist]\n"
+            "v_add_u32 %[vs], %[vs], %[lane]\n"
+            "v_add_u32 %[vw], %[a], %[lane]\n"
+            "v_mov_b32 %[vxb], %[lane]\n"
+            "s_mov_b32 %[sx], 0\n"
+            "Lfchunk_%=:\n"
+            "v_and_b32 %[vq], %[mask], %[vw]\n"
+            "v_add_u32 %[vq], %[ring], %[vq]\n"
+            "v_cmp_gt_u32 vcc, %[slen], %[vxb]\n"
+            "s_mov_b64 exec, vcc\n"
+            "global_load_ubyte %[vx], %[vs], %[gb]\n"
+            "s_waitcnt vmcnt(0)\n"
+            "ds_write_b8 %[vq], %[vx]\n"
+            "s_mov_b64 exec, -1\n"
+            "v_add_u32 %[vs], 64, %[vs]\n"
+            "v_add_u32 %[vw], 64, %[vw]\n"
+            "v_add_u32 %[vxb], 64, %[vxb]\n"
+            "s_add_i32 %[sx], %[sx], 64\n"
+            "s_cmp_lt_u32 %[sx], %[slen]\n"
+            "s_cbranch_scc1 Lfchunk_%=\n"
             "s_add_i32 %[a], %[a], %[slen]\n"
             "s_branch Ltop_%=\n"
             "Lexit2_%=:\n"
@@ -369,7 +434,7 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
               [sn] "=&s"(sn), [st] "=&s"(st), [sx] "=&s"(sx), [slen] "=&s"(slen), [vb] "=&v"(vb), [ve] "=&v"(ve), [vt] "=&v"(vt),
               [vn] "=&v"(vn), [vxb] "=&v"(vxb), [vx] "=&v"(vx), [vd] "=&v"(vd), [vq] "=&v"(vq), [vs] "=&v"(vs), [vw] "=&v"(vw),
               [olen] "=&v"(out_len), [odist] "=&v"(out_dist)
-            : [lim] "s"(lim), [dlim] "s"(dlim), [ring] "s"(ring_lds), [llb] "s"(ll_lds), [dtb] "s"(dt_lds), [r0] "v"(r0), [lane] "v"(lane),
+            : [lim] "s"(lim), [dlim] "s"(dlim), [dspan] "s"(span), [gb] "s"(gbase), [ring] "s"(ring_lds), [llb] "s"(ll_lds), [dtb] "s"(dt_lds), [r0] "v"(r0), [lane] "v"(lane),
               [laneh] "v"(lane_half), [mask] "n"(RING_MASK)
             : "s70", "s71", "s72", "s73", "vcc", "scc", "memory");
         dwords += nref;
