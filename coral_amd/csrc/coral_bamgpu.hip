@@ -228,13 +228,40 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
         const uint32_t span = (uint32_t)(a - a0);
         const uint32_t dlim = span < (uint32_t)(RING_BYTES - 64) ? span : (uint32_t)(RING_BYTES - 64);
         const uint32_t ring_lds = (uint32_t)(uintptr_t)ring, ll_lds = (uint32_t)(uintptr_t)T->ll, dt_lds = (uint32_t)(uintptr_t)T->dt;
-        int state, nref;
-        uint32_t se, sn, st, sx, slen;
+        int state;
+        const int idx_in = idx;
+        uint32_t se, sn, sx, slen;
         uint32_t vb, ve, vt, vn, vxb, vx, vd, vq, vs, vw, out_len, out_dist;
+        // (ring addresses: the ring is aligned to its size, so (x & RING_MASK) | ring is one v_and_or_b32 with the mask in a VGPR)
+#define CORAL_INFL_REFILL                                           \
+            "v_readlane_b32 s72, %[r0], %[idx]\n"                   \
+            "s_mov_b32 s73, 0\n"                                    \
+            "s_lshl_b64 s[72:73], s[72:73], %[bc]\n"                \
+            "s_or_b64 s[70:71], s[70:71], s[72:73]\n"               \
+            "s_add_i32 %[bc], %[bc], 32\n"                          \
+            "s_add_i32 %[idx], %[idx], 1\n"
+#define CORAL_INFL_LOOKUP                                           \
+            "v_mov_b32 %[vb], s70\n"                                \
+            "v_and_b32 %[vt], 0x3ff, %[vb]\n"                       \
+            "v_lshl_add_u32 %[vt], %[vt], 1, %[llb]\n"              \
+            "ds_read_u16 %[ve], %[vt]\n"                            \
+            "s_waitcnt lgkmcnt(0)\n"                                \
+            "v_readfirstlane_b32 %[se], %[ve]\n"                    \
+            "s_bitcmp1_b32 %[se], 4\n"
+#define CORAL_INFL_LITERAL                                          \
+            "s_and_b32 %[sn], %[se], 15\n"                          \
+            "v_mov_b32 %[vt], %[a]\n"                               \
+            "s_lshr_b64 s[70:71], s[70:71], %[sn]\n"                \
+            "v_lshrrev_b32 %[vx], 8, %[ve]\n"                       \
+            "s_sub_i32 %[bc], %[bc], %[sn]\n"                       \
+            "v_and_or_b32 %[vt], %[vt], %[vmask], %[ring]\n"        \
+            "s_mov_b64 exec, 1\n"                                   \
+            "ds_write_b8 %[vt], %[vx]\n"                            \
+            "s_mov_b64 exec, -1\n"                                  \
+            "s_add_i32 %[a], %[a], 1\n"
         asm volatile(
             "s_mov_b64 s[70:71], %[bb]\n"
-            "s_mov_b32 %[nref], 0\n"
-            "s_mov_b32 %[slen], 0\n"
+            "v_mov_b32 %[olen], 0\n"
             "v_mov_b32 %[odist], 0\n"
             "Ltop_%=:\n"
             "s_cmp_ge_i32 %[a], %[lim]\n"
@@ -243,99 +270,52 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
             "s_cbranch_scc1 Lsym_%=\n"
             "s_cmp_eq_u32 %[idx], 63\n"
             "s_cbranch_scc1 Lexit0_%=\n"
-            "v_readlane_b32 s72, %[r0], %[idx]\n"
-            "s_mov_b32 s73, 0\n"
-            "s_lshl_b64 s[72:73], s[72:73], %[bc]\n"
-            "s_or_b64 s[70:71], s[70:71], s[72:73]\n"
-            "s_add_i32 %[bc], %[bc], 32\n"
-            "s_add_i32 %[idx], %[idx], 1\n"
-            "s_add_i32 %[nref], %[nref], 1\n"
+            CORAL_INFL_REFILL
             "Lsym_%=:\n"                                       // more than 32 bits: first table look-up of the round
-            "v_mov_b32 %[vb], s70\n"
-            "v_and_b32 %[vt], 0x3ff, %[vb]\n"
-            "v_lshl_add_u32 %[vt], %[vt], 1, %[llb]\n"
-            "ds_read_u16 %[ve], %[vt]\n"
-            "s_waitcnt lgkmcnt(0)\n"
-            "v_readfirstlane_b32 %[se], %[ve]\n"
-            "s_bitcmp1_b32 %[se], 4\n"
+            CORAL_INFL_LOOKUP
             "s_cbranch_scc1 Lnotlit_%=\n"
-            "s_and_b32 %[sn], %[se], 15\n"                     // literal
-            "s_lshr_b64 s[70:71], s[70:71], %[sn]\n"
-            "s_sub_i32 %[bc], %[bc], %[sn]\n"
-            "v_lshrrev_b32 %[vx], 8, %[ve]\n"
-            "s_and_b32 %[st], %[a], %[mask]\n"
-            "s_add_i32 %[st], %[st], %[ring]\n"
-            "v_mov_b32 %[vt], %[st]\n"
-            "s_mov_b64 exec, 1\n"                              // one lane writes (64 lanes storing to one address are 64 LDS accesses)
-            "ds_write_b8 %[vt], %[vx]\n"
-            "s_mov_b64 exec, -1\n"
-            "s_add_i32 %[a], %[a], 1\n"
-            "v_mov_b32 %[vb], s70\n"                           // at least 23 bits left: second look-up without a refill check
-            "v_and_b32 %[vt], 0x3ff, %[vb]\n"
-            "v_lshl_add_u32 %[vt], %[vt], 1, %[llb]\n"
-            "ds_read_u16 %[ve], %[vt]\n"
-            "s_waitcnt lgkmcnt(0)\n"
-            "v_readfirstlane_b32 %[se], %[ve]\n"
-            "s_bitcmp1_b32 %[se], 4\n"
+            CORAL_INFL_LITERAL                                 // (one lane stores: 64 lanes storing to one address are 64 LDS accesses)
+            CORAL_INFL_LOOKUP                                  // at least 23 bits left: second look-up without a refill check
             "s_cbranch_scc1 Lnotlit_%=\n"
-            "s_and_b32 %[sn], %[se], 15\n"                     // second literal
-            "s_lshr_b64 s[70:71], s[70:71], %[sn]\n"
-            "s_sub_i32 %[bc], %[bc], %[sn]\n"
-            "v_lshrrev_b32 %[vx], 8, %[ve]\n"
-            "s_and_b32 %[st], %[a], %[mask]\n"
-            "s_add_i32 %[st], %[st], %[ring]\n"
-            "v_mov_b32 %[vt], %[st]\n"
-            "s_mov_b64 exec, 1\n"                              // one lane writes (64 lanes storing to one address are 64 LDS accesses)
-            "ds_write_b8 %[vt], %[vx]\n"
-            "s_mov_b64 exec, -1\n"
-            "s_add_i32 %[a], %[a], 1\n"
+            CORAL_INFL_LITERAL
             "s_branch Ltop_%=\n"
-            "Lnotlit_%=:\n"                                    // se = table entry, s70 = the bits it was looked up with (>= 23)
+            "Lnotlit_%=:\n"                                    // ve / se = table entry, vb = the bits it was looked up with (>= 23)
             "s_and_b32 %[sn], %[se], 15\n"
+            "v_and_b32 %[vn], 15, %[ve]\n"
+            "v_bfe_u32 %[vxb], %[ve], 5, 3\n"                  // extra bits of the length code
             "s_cmp_eq_u32 %[sn], 0\n"
-            "s_cbranch_scc1 Lexit0_%=\n"                       // not in the table
-            "s_bfe_u32 %[sx], %[se], 0x30005\n"                // extra bits of the length code
-            "s_lshr_b32 %[slen], %[se], 8\n"                   // length base - 3
-            "s_lshr_b32 %[st], s70, %[sn]\n"
-            "s_bfm_b32 s72, %[sx], 0\n"
-            "s_and_b32 %[st], %[st], s72\n"
-            "s_add_i32 %[slen], %[slen], %[st]\n"
-            "s_add_i32 %[slen], %[slen], 3\n"
-            "s_add_i32 %[sn], %[sn], %[sx]\n"
+            "v_bfe_u32 %[vt], %[vb], %[vn], %[vxb]\n"
+            "v_lshrrev_b32 %[vx], 8, %[ve]\n"                  // length base - 3
+            "s_cbranch_scc1 Lexit0_%=\n"                       // not in the table (nothing consumed)
+            "v_add_u32 %[vn], %[vn], %[vxb]\n"
+            "v_add3_u32 %[olen], %[vx], %[vt], 3\n"
+            "v_readfirstlane_b32 %[sn], %[vn]\n"               // (one instruction between the VALU write and this read)
             "s_lshr_b64 s[70:71], s[70:71], %[sn]\n"
             "s_sub_i32 %[bc], %[bc], %[sn]\n"
+            "v_readfirstlane_b32 %[slen], %[olen]\n"
             "s_cmp_gt_i32 %[bc], 32\n"                         // the distance code needs up to 8 + 13 bits
             "s_cbranch_scc1 Ldist_%=\n"
             "s_cmp_eq_u32 %[idx], 63\n"
             "s_cbranch_scc1 Lexit1_%=\n"
-            "v_readlane_b32 s72, %[r0], %[idx]\n"
-            "s_mov_b32 s73, 0\n"
-            "s_lshl_b64 s[72:73], s[72:73], %[bc]\n"
-            "s_or_b64 s[70:71], s[70:71], s[72:73]\n"
-            "s_add_i32 %[bc], %[bc], 32\n"
-            "s_add_i32 %[idx], %[idx], 1\n"
-            "s_add_i32 %[nref], %[nref], 1\n"
+            CORAL_INFL_REFILL
             "Ldist_%=:\n"
             "v_mov_b32 %[vb], s70\n"
             "v_and_b32 %[vt], 0xff, %[vb]\n"
             "v_lshl_add_u32 %[vt], %[vt], 2, %[dtb]\n"
             "ds_read_b32 %[vd], %[vt]\n"
             "s_waitcnt lgkmcnt(0)\n"
-            "v_readfirstlane_b32 %[se], %[vd]\n"
             "v_and_b32 %[vn], 15, %[vd]\n"
             "v_bfe_u32 %[vxb], %[vd], 8, 4\n"
             "v_lshrrev_b32 %[vx], 16, %[vd]\n"
             "v_bfe_u32 %[vt], %[vb], %[vn], %[vxb]\n"
-            "v_add_u32 %[odist], %[vx], %[vt]\n"
-            "s_and_b32 %[sn], %[se], 15\n"
-            "s_cmp_eq_u32 %[sn], 0\n"
-            "s_cbranch_scc1 Lexit1_%=\n"                       // distance code not in the table (nothing of it consumed)
-            "s_bfe_u32 %[sx], %[se], 0x40008\n"
-            "s_add_i32 %[sn], %[sn], %[sx]\n"
+            "v_add_u32 %[vn], %[vn], %[vxb]\n"
+            "v_add_u32 %[odist], %[vx], %[vt]\n"               // a code that is not in the table has entry 0: distance 0, no bits
+            "v_readfirstlane_b32 %[sn], %[vn]\n"
+            "v_add_u32 %[vt], -1, %[odist]\n"
             "s_lshr_b64 s[70:71], s[70:71], %[sn]\n"
             "s_sub_i32 %[bc], %[bc], %[sn]\n"
-            "v_cmp_lt_u32 vcc, %[dlim], %[odist]\n"            // behind the ring, or maybe in front of the block's first byte
-            "s_cbranch_vccnz Lfarq_%=\n"
+            "v_cmp_le_u32 vcc, %[dlim], %[vt]\n"               // dist - 1 >= dlim: not in the table (0), behind the ring, or maybe
+            "s_cbranch_vccnz Lfarq_%=\n"                       // in front of the block's first byte
             "s_cmp_gt_u32 %[slen], 64\n"
             "s_cbranch_scc1 Llong_%=\n"
             "v_cvt_f32_u32 %[vq], %[odist]\n"                  // byte k of the match = byte (k mod dist) of the dist bytes in front
@@ -347,10 +327,8 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
             "v_mul_lo_u32 %[vq], %[vq], %[odist]\n"
             "v_sub_u32 %[vq], %[lane], %[vq]\n"
             "v_add_u32 %[vs], %[vs], %[vq]\n"
-            "v_and_b32 %[vs], %[mask], %[vs]\n"
-            "v_add_u32 %[vs], %[ring], %[vs]\n"
-            "v_and_b32 %[vw], %[mask], %[vw]\n"
-            "v_add_u32 %[vw], %[ring], %[vw]\n"
+            "v_and_or_b32 %[vs], %[vs], %[vmask], %[ring]\n"
+            "v_and_or_b32 %[vw], %[vw], %[vmask], %[ring]\n"
             "v_cmp_gt_u32 vcc, %[slen], %[lane]\n"
             "s_mov_b64 exec, vcc\n"
             "ds_read_u8 %[vx], %[vs]\n"
@@ -374,11 +352,9 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
             "v_cndmask_b32 %[vq], %[vxb], %[vq], vcc\n"        // dist >= 64: k itself
             "v_sub_u32 %[vs], %[a], %[odist]\n"
             "v_add_u32 %[vs], %[vs], %[vq]\n"
-            "v_and_b32 %[vs], %[mask], %[vs]\n"
-            "v_add_u32 %[vs], %[ring], %[vs]\n"
+            "v_and_or_b32 %[vs], %[vs], %[vmask], %[ring]\n"
             "v_add_u32 %[vw], %[a], %[vxb]\n"
-            "v_and_b32 %[vw], %[mask], %[vw]\n"
-            "v_add_u32 %[vw], %[ring], %[vw]\n"
+            "v_and_or_b32 %[vw], %[vw], %[vmask], %[ring]\n"
             "v_cmp_gt_u32 vcc, %[slen], %[vxb]\n"
             "s_mov_b64 exec, vcc\n"
             "ds_read_u8 %[vx], %[vs]\n"
@@ -393,6 +369,8 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
             "s_add_i32 %[a], %[a], %[slen]\n"
             "s_branch Ltop_%=\n"
             "Lfarq_%=:\n"
+            "v_cmp_eq_u32 vcc, 0, %[odist]\n"                  // distance code not in the table (nothing of it consumed)
+            "s_cbranch_vccnz Lexit1_%=\n"
             "v_cmp_lt_u32 vcc, %[dspan], %[odist]\n"           // further back than this call's first output byte was from the
             "s_cbranch_vccnz Lexit2_%=\n"                      // block's start: the general path tells a bad distance from a good one
             // the source has left the ring (dist > RING_BYTES - 64): it is in global memory, drained up to the last 256-byte line
@@ -403,8 +381,7 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
             "v_mov_b32 %[vxb], %[lane]\n"
             "s_mov_b32 %[sx], 0\n"
             "Lfchunk_%=:\n"
-            "v_and_b32 %[vq], %[mask], %[vw]\n"
-            "v_add_u32 %[vq], %[ring], %[vq]\n"
+            "v_and_or_b32 %[vq], %[vw], %[vmask], %[ring]\n"
             "v_cmp_gt_u32 vcc, %[slen], %[vxb]\n"
             "s_mov_b64 exec, vcc\n"
             "global_load_ubyte %[vx], %[vs], %[gb]\n"
@@ -428,16 +405,17 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
             "Lexit0_%=:\n"
             "s_mov_b32 %[state], 0\n"
             "Lout_%=:\n"
-            "v_mov_b32 %[olen], %[slen]\n"
             "s_mov_b64 %[bb], s[70:71]\n"
-            : [bb] "+s"(bb), [bc] "+s"(bc), [idx] "+s"(idx), [a] "+s"(a), [state] "=&s"(state), [nref] "=&s"(nref), [se] "=&s"(se),
-              [sn] "=&s"(sn), [st] "=&s"(st), [sx] "=&s"(sx), [slen] "=&s"(slen), [vb] "=&v"(vb), [ve] "=&v"(ve), [vt] "=&v"(vt),
-              [vn] "=&v"(vn), [vxb] "=&v"(vxb), [vx] "=&v"(vx), [vd] "=&v"(vd), [vq] "=&v"(vq), [vs] "=&v"(vs), [vw] "=&v"(vw),
-              [olen] "=&v"(out_len), [odist] "=&v"(out_dist)
-            : [lim] "s"(lim), [dlim] "s"(dlim), [dspan] "s"(span), [gb] "s"(gbase), [ring] "s"(ring_lds), [llb] "s"(ll_lds), [dtb] "s"(dt_lds), [r0] "v"(r0), [lane] "v"(lane),
-              [laneh] "v"(lane_half), [mask] "n"(RING_MASK)
+            : [bb] "+s"(bb), [bc] "+s"(bc), [idx] "+s"(idx), [a] "+s"(a), [state] "=&s"(state), [se] "=&s"(se), [sn] "=&s"(sn),
+              [sx] "=&s"(sx), [slen] "=&s"(slen), [vb] "=&v"(vb), [ve] "=&v"(ve), [vt] "=&v"(vt), [vn] "=&v"(vn), [vxb] "=&v"(vxb),
+              [vx] "=&v"(vx), [vd] "=&v"(vd), [vq] "=&v"(vq), [vs] "=&v"(vs), [vw] "=&v"(vw), [olen] "=&v"(out_len), [odist] "=&v"(out_dist)
+            : [lim] "s"(lim), [dlim] "s"(dlim), [dspan] "s"(span), [gb] "s"(gbase), [ring] "s"(ring_lds), [llb] "s"(ll_lds), [dtb] "s"(dt_lds),
+              [r0] "v"(r0), [lane] "v"(lane), [laneh] "v"(lane_half), [vmask] "v"((uint32_t)RING_MASK)
             : "s70", "s71", "s72", "s73", "vcc", "scc", "memory");
-        dwords += nref;
+#undef CORAL_INFL_REFILL
+#undef CORAL_INFL_LOOKUP
+#undef CORAL_INFL_LITERAL
+        dwords += idx - idx_in;                             // (the input register is only switched by the general path)
         lenv = out_len;
         distv = out_dist;
         return state;
@@ -480,11 +458,16 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
 typedef DevWaveT<0> DevWave;
 
 #define INFL_WAVES 1                     // one wave per workgroup: LDS (tables + ring, 7.7 KiB) is allocated per wave
+#ifdef INFL_WAVES_PER_EU                  // (occupancy experiments: caps the kernel's VGPRs so that this many waves fit a SIMD)
+#define INFL_OCCUPANCY __attribute__((amdgpu_waves_per_eu(INFL_WAVES_PER_EU, INFL_WAVES_PER_EU)))
+#else
+#define INFL_OCCUPANCY
+#endif
 template <int ABLATE>
-__global__ __launch_bounds__(INFL_WAVES *WAVE) void k_bgzf_inflate(const uint8_t *__restrict__ comp, const BlockDesc *__restrict__ desc,
+__global__ __launch_bounds__(INFL_WAVES *WAVE) INFL_OCCUPANCY void k_bgzf_inflate(const uint8_t *__restrict__ comp, const BlockDesc *__restrict__ desc,
                                                                      int n_blocks, uint8_t *out, int32_t *__restrict__ status) {
     __shared__ coral_inflate::Tables tables[INFL_WAVES];
-    __shared__ __attribute__((aligned(16))) uint8_t rings[INFL_WAVES][RING_BYTES];
+    __shared__ __attribute__((aligned(RING_BYTES))) uint8_t rings[INFL_WAVES][RING_BYTES];      // (DevWaveT::fast relies on the alignment)
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int b = blockIdx.x * INFL_WAVES + wib;
