@@ -316,19 +316,14 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
             "s_sub_i32 %[bc], %[bc], %[sn]\n"
             "v_cmp_le_u32 vcc, %[dlim], %[vt]\n"               // dist - 1 >= dlim: not in the table (0), behind the ring, or maybe
             "s_cbranch_vccnz Lfarq_%=\n"                       // in front of the block's first byte
-            "s_cmp_gt_u32 %[slen], 64\n"
-            "s_cbranch_scc1 Llong_%=\n"
-            "v_cvt_f32_u32 %[vq], %[odist]\n"                  // byte k of the match = byte (k mod dist) of the dist bytes in front
-            "v_rcp_f32 %[vq], %[vq]\n"
+            "v_min_u32 %[vt], 64, %[odist]\n"                  // longer than 64 bytes, or overlapping its own source (dist < len):
+            "v_cmp_lt_u32 vcc, %[vt], %[olen]\n"               // the general copy below; otherwise byte k comes from a - dist + k
+            "s_cbranch_vccnz Llong_%=\n"
             "v_sub_u32 %[vs], %[a], %[odist]\n"
             "v_add_u32 %[vw], %[a], %[lane]\n"
-            "v_mul_f32 %[vq], %[laneh], %[vq]\n"               // floor((lane + 0.5) / dist): exact (DevWaveT::match); 0 for dist >= 64
-            "v_cvt_u32_f32 %[vq], %[vq]\n"
-            "v_mul_lo_u32 %[vq], %[vq], %[odist]\n"
-            "v_sub_u32 %[vq], %[lane], %[vq]\n"
-            "v_add_u32 %[vs], %[vs], %[vq]\n"
-            "v_and_or_b32 %[vs], %[vs], %[vmask], %[ring]\n"
+            "v_add_u32 %[vs], %[vs], %[lane]\n"
             "v_and_or_b32 %[vw], %[vw], %[vmask], %[ring]\n"
+            "v_and_or_b32 %[vs], %[vs], %[vmask], %[ring]\n"
             "v_cmp_gt_u32 vcc, %[slen], %[lane]\n"
             "s_mov_b64 exec, vcc\n"
             "ds_read_u8 %[vx], %[vs]\n"
@@ -337,8 +332,9 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
             "s_mov_b64 exec, -1\n"
             "s_add_i32 %[a], %[a], %[slen]\n"
             "s_branch Ltop_%=\n"
-            "Llong_%=:\n"                                      // 65..258 bytes, source in the ring: chunks of 64 in order (a chunk may
-            "v_cvt_f32_u32 %[vq], %[odist]\n"                  // read what the chunk before it wrote: LDS operations of a wave execute in order)
+            "Llong_%=:\n"                                      // source in the ring, any length: byte k of the match = byte (k mod dist) of the
+            "v_cvt_f32_u32 %[vq], %[odist]\n"                  // dist bytes in front; chunks of 64 in order (a chunk may read what the chunk
+                                                               // before it wrote: LDS operations of a wave execute in order)
             "v_rcp_f32 %[vn], %[vq]\n"
             "v_mov_b32 %[vxb], %[lane]\n"                      // k
             "v_mov_b32 %[vd], %[laneh]\n"                      // k + 0.5
@@ -347,7 +343,7 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
             "v_mul_f32 %[vq], %[vd], %[vn]\n"
             "v_cvt_u32_f32 %[vq], %[vq]\n"
             "v_mul_lo_u32 %[vq], %[vq], %[odist]\n"
-            "v_sub_u32 %[vq], %[vxb], %[vq]\n"                 // k mod dist (when dist < 64)
+            "v_sub_u32 %[vq], %[vxb], %[vq]\n"                 // k mod dist (when dist < 64): floor((k + 0.5) / dist) is exact (DevWaveT::match)
             "v_cmp_gt_u32 vcc, 64, %[odist]\n"
             "v_cndmask_b32 %[vq], %[vxb], %[vq], vcc\n"        // dist >= 64: k itself
             "v_sub_u32 %[vs], %[a], %[odist]\n"
