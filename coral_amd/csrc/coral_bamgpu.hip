@@ -207,8 +207,9 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
         a += len;
     }
     // The hot path of the symbol loop, by hand (gfx950 ISA).  The compiler turns Inflater::codes_vector into a state machine of
-    // boolean SGPR pairs and register copies at every join (≈42 scalar + 13 branch instructions per symbol, and the CU's one
-    // scalar pipe is what bounds the kernel); this loop spends ≈13 scalar instructions on a literal and ≈30 on a match.  It takes
+    // boolean SGPR pairs and register copies at every join (≈42 scalar + 13 branch + 35 vector instructions per symbol); this loop
+    // needs ≈20 + 7 + 24 (rocprofv3 counters): a literal is 9 scalar + 8 vector instructions behind its table
+    // look-up, a short match ≈20 + 25.  It takes
     // what is common — literal / length / distance codes found in the LDS tables, refills from the current input register,
     // every match whose distance is known to lie inside the block (from the ring, or from global memory once the source has left
     // the ring) — and RETURNS, with nothing half-done, where it cannot go on:
