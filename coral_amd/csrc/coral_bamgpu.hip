@@ -213,8 +213,9 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
     // what is common — literal / length / distance codes found in the LDS tables, refills from the current input register,
     // every match whose distance is known to lie inside the block (from the ring, or from global memory once the source has left
     // the ring) — and RETURNS, with nothing half-done, where it cannot go on:
-    //   0  at a symbol boundary: `a` reached `lim` (a line of output is complete, or the block's last 260 bytes begin, or fail()
-    //      asked for a stop), the refill would switch the input register, or the code is not in the table (long code, end of block)
+    //   0  at a symbol boundary: the block's last 260 bytes begin, its first (partial) line is complete or fail() asked for a stop
+    //      (completed whole lines are written to global memory inside the loop), the refill would switch the input register, or
+    //      the code is not in the table (long code, end of block)
     //   1  a length has been read (lenv) and the input register must be switched, or the distance code is not in the table
     //   2  length and distance have been read (lenv, distv), but the distance reaches further back than this call's first byte
     //      was from the block's start (`span` is taken at entry: a distance the general path accepts may come back here, never
@@ -225,7 +226,7 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
     // v_readfirstlane needs one wait state, a transcendental result (v_rcp_f32) read by another VALU instruction one.
     static constexpr bool has_fast = (ABLATE == 0);
     __device__ __forceinline__ int fast(uint64_t &bb, int &bc, long long &dwords, const coral_inflate::Tables *T, uint32_t &lenv, uint32_t &distv) {
-        const int lim = attend < aend - 260 ? attend : aend - 260;
+        int lim = attend < aend - 260 ? attend : aend - 260;
         const uint32_t span = (uint32_t)(a - a0);
         const uint32_t dlim = span < (uint32_t)(RING_BYTES - 64) ? span : (uint32_t)(RING_BYTES - 64);
         const uint32_t ring_lds = (uint32_t)(uintptr_t)ring, ll_lds = (uint32_t)(uintptr_t)T->ll, dt_lds = (uint32_t)(uintptr_t)T->dt;
@@ -266,7 +267,8 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
             "v_mov_b32 %[odist], 0\n"
             "Ltop_%=:\n"
             "s_cmp_ge_i32 %[a], %[lim]\n"
-            "s_cbranch_scc1 Lexit0_%=\n"
+            "s_cbranch_scc1 Lattn_%=\n"
+            "Lbits_%=:\n"
             "s_cmp_gt_i32 %[bc], 32\n"
             "s_cbranch_scc1 Lsym_%=\n"
             "s_cmp_eq_u32 %[idx], 63\n"
@@ -393,6 +395,32 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
             "s_cbranch_scc1 Lfchunk_%=\n"
             "s_add_i32 %[a], %[a], %[slen]\n"
             "s_branch Ltop_%=\n"
+            "Lattn_%=:\n"                                      // a >= lim.  Completed 256-byte lines go ring -> global memory right here
+            "s_cmp_lt_i32 %[a], %[attend]\n"                  // (one dword per lane, DevWaveT::drain) unless the block's last bytes
+            "s_cbranch_scc1 Lexit0_%=\n"                       // begin, the block's first line is a partial one, or fail() moved `attend`
+            "s_cmp_gt_i32 %[a], %[aendz]\n"
+            "s_cbranch_scc1 Lexit0_%=\n"
+            "s_and_b32 %[sn], %[gdone], 255\n"
+            "s_cmp_lg_u32 %[sn], 0\n"
+            "s_cbranch_scc1 Lexit0_%=\n"
+            "s_add_i32 %[sx], %[gdone], 256\n"
+            "s_cmp_lg_u32 %[sx], %[attend]\n"
+            "s_cbranch_scc1 Lexit0_%=\n"
+            "Ldrain_%=:\n"
+            "v_lshl_add_u32 %[vt], %[lane], 2, %[gdone]\n"
+            "v_and_or_b32 %[vs], %[vt], %[vmask], %[ring]\n"
+            "ds_read_b32 %[vx], %[vs]\n"
+            "s_mov_b32 %[gdone], %[sx]\n"
+            "s_add_i32 %[sx], %[sx], 256\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "global_store_dword %[vt], %[vx], %[gb]\n"
+            "s_cmp_le_i32 %[sx], %[a]\n"
+            "s_cbranch_scc1 Ldrain_%=\n"
+            "s_mov_b32 %[attend], %[sx]\n"                     // = (gdone | 255) + 1
+            "s_min_i32 %[lim], %[sx], %[aendz]\n"
+            "s_cmp_ge_i32 %[a], %[lim]\n"                      // (only when the block's last 260 bytes have begun)
+            "s_cbranch_scc1 Lexit0_%=\n"
+            "s_branch Lbits_%=\n"
             "Lexit2_%=:\n"
             "s_mov_b32 %[state], 2\n"
             "s_branch Lout_%=\n"
@@ -403,10 +431,10 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
             "s_mov_b32 %[state], 0\n"
             "Lout_%=:\n"
             "s_mov_b64 %[bb], s[70:71]\n"
-            : [bb] "+s"(bb), [bc] "+s"(bc), [idx] "+s"(idx), [a] "+s"(a), [state] "=&s"(state), [se] "=&s"(se), [sn] "=&s"(sn),
+            : [bb] "+s"(bb), [bc] "+s"(bc), [idx] "+s"(idx), [a] "+s"(a), [gdone] "+s"(gdone), [attend] "+s"(attend), [lim] "+s"(lim), [state] "=&s"(state), [se] "=&s"(se), [sn] "=&s"(sn),
               [sx] "=&s"(sx), [slen] "=&s"(slen), [vb] "=&v"(vb), [ve] "=&v"(ve), [vt] "=&v"(vt), [vn] "=&v"(vn), [vxb] "=&v"(vxb),
               [vx] "=&v"(vx), [vd] "=&v"(vd), [vq] "=&v"(vq), [vs] "=&v"(vs), [vw] "=&v"(vw), [olen] "=&v"(out_len), [odist] "=&v"(out_dist)
-            : [lim] "s"(lim), [dlim] "s"(dlim), [dspan] "s"(span), [gb] "s"(gbase), [ring] "s"(ring_lds), [llb] "s"(ll_lds), [dtb] "s"(dt_lds),
+            : [aendz] "s"(aend - 260), [dlim] "s"(dlim), [dspan] "s"(span), [gb] "s"(gbase), [ring] "s"(ring_lds), [llb] "s"(ll_lds), [dtb] "s"(dt_lds),
               [r0] "v"(r0), [lane] "v"(lane), [laneh] "v"(lane_half), [vmask] "v"((uint32_t)RING_MASK)
             : "s70", "s71", "s72", "s73", "vcc", "scc", "memory");
 #undef CORAL_INFL_REFILL
