@@ -482,7 +482,9 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
 
 typedef DevWaveT<0> DevWave;
 
+#ifndef INFL_WAVES
 #define INFL_WAVES 1                     // one wave per workgroup: LDS (tables + ring, 7.7 KiB) is allocated per wave
+#endif
 #ifdef INFL_WAVES_PER_EU                  // (occupancy experiments: caps the kernel's VGPRs so that this many waves fit a SIMD)
 #define INFL_OCCUPANCY __attribute__((amdgpu_waves_per_eu(INFL_WAVES_PER_EU, INFL_WAVES_PER_EU)))
 #else
