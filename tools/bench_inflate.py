@@ -5,6 +5,9 @@ sys.path.insert(0, ".")
 import numpy as np, torch
 from coral_amd import bam, synth, _lib
 
+if os.environ.get('CORAL_LIB'):       # a variant build (ring size / occupancy experiments); before ANYTHING loads the library:
+    _lib.LIB_PATH = os.path.abspath(os.environ['CORAL_LIB'])      # _lib.lib() caches the first library it opens
+    print("library under test:", _lib.LIB_PATH, file=sys.stderr)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
 level = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 5
@@ -21,8 +24,6 @@ while at + 18 <= len(raw):
     desc.append((at + 12 + xlen, bsize - 12 - xlen - 8, out_off, isize))
     out_off += isize
     at += bsize
-if os.environ.get('CORAL_LIB'):
-    _lib.LIB_PATH = os.path.abspath(os.environ['CORAL_LIB'])      # a variant build (ring size experiments)
 L = _lib.lib()
 dev = "cuda:0"
 comp = torch.from_numpy(np.concatenate([raw, np.zeros(4096, dtype=np.uint8)])).to(dev)
