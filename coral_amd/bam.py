@@ -108,7 +108,7 @@ def decode_bam_gpu(path: str, device="cuda:0", n_threads: Optional[int] = None, 
                    batch_bytes: int = 0) -> Records:
     """The same result as ``decode_bam`` with the inflate and the record parsing on the GPU (csrc/coral_bamgpu.hip): the host
     only reads the file and uploads COMPRESSED bytes; the CIGAR words of the returned Records are a device tensor (they never
-    exist in host memory), everything else is host-side as before.  ``batch_bytes``: inflated bytes per batch (0 = the default, 2.43 GiB)."""
+    exist in host memory), everything else is host-side as before.  ``batch_bytes``: inflated bytes per batch (0 = the default, 2.52 GiB)."""
     L = _lib.lib()
     dev = torch.device(device)
     if dev.type != "cuda":

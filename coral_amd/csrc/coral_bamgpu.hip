@@ -18,7 +18,7 @@
 //                   codes, read name and SA text -> compact blobs for the host
 //   worker thread   per batch, a few hundred bytes per record: read names -> ids, SA text -> numeric rows; the rare
 //                   records with non-ACGT bases are gathered whole (k_bam_gather) and handled by the CPU pipeline's own routine.
-// Batches (64 MiB first, doubling up to 2.43 GiB inflated, coral_bamgpu_open) are double-buffered: while batch k is parsed, batch k + 1 is inflated
+// Batches (64 MiB first, doubling up to 2.52 GiB inflated, coral_bamgpu_open) are double-buffered: while batch k is parsed, batch k + 1 is inflated
 // and k + 2 is read.
 // A record that straddles two batches is carried in front of the next batch's buffer.
 //
@@ -56,7 +56,7 @@ struct BlockDesc {
 // K_inflate
 // ---------------------------------------------------------------------------------------------
 #ifndef RING_LOG
-#define RING_LOG 11                      // 2 KiB: with the tables 6.1 KiB of LDS per wave -> 26 waves per CU (4 KiB: 19 waves, +14 % time:
+#define RING_LOG 11                      // 2 KiB: with the tables 5.75 KiB of LDS per wave -> 27 waves per CU (4 KiB: 19 waves, +14 % time:
 #endif                                   // the kernel is bound by the latency of its LDS round trips, profiles/r03_pmc_inflate.md)
 #define RING_BYTES (1 << RING_LOG)       // recent output per wave, in LDS: LZ77 matches read it instead of global memory
 #define RING_MASK (RING_BYTES - 1)
@@ -483,7 +483,7 @@ _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
 typedef DevWaveT<0> DevWave;
 
 #ifndef INFL_WAVES
-#define INFL_WAVES 1                     // one wave per workgroup: LDS (tables + ring, 6.1 KiB) is allocated per wave
+#define INFL_WAVES 1                     // one wave per workgroup: LDS (tables + ring, 5.75 KiB) is allocated per wave
 #endif
 #ifdef INFL_WAVES_PER_EU                  // (occupancy experiments: caps the kernel's VGPRs so that this many waves fit a SIMD)
 #define INFL_OCCUPANCY __attribute__((amdgpu_waves_per_eu(INFL_WAVES_PER_EU, INFL_WAVES_PER_EU)))
@@ -545,20 +545,23 @@ __global__ __launch_bounds__(INFL_WAVES *WAVE) INFL_OCCUPANCY void k_bgzf_inflat
 // 16-byte loads, so a cache line is fetched once by the one lane that owns it — with 4-byte loads at a 1 KB lane stride every
 // line was touched sixteen times; (ii) four 256-entry tables in LDS (slicing by 4): the four look-ups of a dword are independent
 // instead of a chain of four; (iii) the kernel runs on a stream of its own, next to the following batch's inflate.
-__global__ __launch_bounds__(256) void k_bgzf_crc(const uint8_t *__restrict__ out, const BlockDesc *__restrict__ desc, const uint32_t *__restrict__ want,
-                                                   int n_blocks, int32_t *__restrict__ status) {
+// One-wave workgroups (as every kernel that runs beside the next batch's inflate launch): that launch keeps 27 waves per CU
+// resident — 7 + 7 + 7 + 6 on the four SIMDs, 504 of 512 VGPRs on the full ones — so a four-wave workgroup, which needs room on
+// all four SIMDs at once, only started when the inflate launch was nearly over (rocprofv3 timeline: 25 ms instead of 1 ms);
+// its 4 KiB of tables fit the LDS the inflate waves leave (27 x 5 888 B of 160 KiB).
+__global__ __launch_bounds__(WAVE) void k_bgzf_crc(const uint8_t *__restrict__ out, const BlockDesc *__restrict__ desc, const uint32_t *__restrict__ want,
+                                                    int n_blocks, int32_t *__restrict__ status) {
     __shared__ uint32_t T[4][256];
-    {
-        const uint32_t i = threadIdx.x;
-        uint32_t c = coral_crc::table_entry(i);
-        T[0][i] = c;
-        __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 256u; i += WAVE) T[0][i] = coral_crc::table_entry(i);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 256u; i += WAVE) {
+        uint32_t c = T[0][i];
         for (int k = 1; k < 4; ++k) {                     // T[k][i] = T[0][i] followed by k zero bytes
             c = (c >> 8) ^ T[0][c & 0xffu];
             T[k][i] = c;
         }
-        __syncthreads();
     }
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int b = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (b >= n_blocks) return;
@@ -727,41 +730,46 @@ __global__ __launch_bounds__(WAVE) void k_bam_verify(const uint8_t *__restrict__
     int error = 0, done = 0;
     const int s_end = seg0 + n_seg;
     // The walk is serial (the next segment is where this one's records land), but its memory round trips need not be: lane k
-    // loads the guess of segment sb + k, and the chain is followed through those 64 segments in registers (round 3: one
-    // dependent round trip per segment was 6 ms per 2.4 GiB batch, on the parse stream's critical path)
+    // loads the guess of segment sb + k, and the chain is followed through those 64 segments in registers with v_readlane.
+    // Positions inside a batch fit 32 bits (coral_bamgpu_open keeps CARRY_CAP + the batch below 4 GiB), which halves the
+    // arithmetic of the loop — one wave, one instruction at a time: the instruction count IS the time (round 3: one dependent
+    // round trip and ~140 instructions per segment were 6 ms per 2.4 GiB batch, on the parse stream's critical path).
+    const uint32_t lim32 = limit > 0xffffffffll ? 0xffffffffu : (uint32_t)limit, end32 = (uint32_t)data_end;
+    uint32_t c32 = (uint32_t)cur;
     for (bool stop = false; !stop;) {
-        if (cur >= limit) { done = 1; break; }
-        if (cur + 4 > data_end) break;
-        const int sb = (int)(cur / SEG_BYTES), sl = sb + lane;
+        if (c32 >= lim32) { done = 1; break; }
+        if ((unsigned long long)c32 + 4 > (unsigned long long)data_end) break;
+        const int sb = (int)(c32 / (uint32_t)SEG_BYTES), sl = sb + lane;
         const bool have = sl < s_end;
-        const long long f_l = have ? seg_first[sl] : -1, land_l = have ? seg_land[sl] : -1;
-        const int cnt_l = have ? seg_count[sl] : 0;
+        const long long f64 = have ? seg_first[sl] : -1, land64 = have ? seg_land[sl] : -1;
+        const int f_l = f64 < 0 ? -1 : (int)(uint32_t)f64;             // (a position is never 0xffffffff: it would lie beyond data_end)
+        const int land_l = (int)(uint32_t)land64, cnt_l = have ? seg_count[sl] : 0;
         long long base_l = 0;
         bool visited_l = false;
         for (;;) {
-            if (cur >= limit) { done = 1; stop = true; break; }
-            if (cur + 4 > data_end) { stop = true; break; }
-            const int s = (int)(cur / SEG_BYTES), k = s - sb;
+            const int k = __builtin_amdgcn_readfirstlane((int)(c32 / (uint32_t)SEG_BYTES) - sb);
             if (k >= WAVE) break;                        // the next 64 segments
-            const long long seg_end = min((long long)(s + 1) * SEG_BYTES, data_end);
-            const long long f = __shfl(f_l, k);
-            long long land = __shfl(land_l, k);
-            int cnt = __shfl(cnt_l, k);
-            if (f != cur) {                              // the guess is not on the chain (or there was none): exact walk
+            const uint32_t seg_end = min((uint32_t)(sb + k + 1) * (uint32_t)SEG_BYTES - 1u, end32 - 1u) + 1u;    // (no overflow at 4 GiB)
+            uint32_t land = (uint32_t)__builtin_amdgcn_readlane(land_l, k);
+            int cnt = __builtin_amdgcn_readlane(cnt_l, k);
+            if ((uint32_t)__builtin_amdgcn_readlane(f_l, k) != c32) {           // the guess is not on the chain (or there was none): exact walk
                 int err = 0;
-                land = hop(buf, cur, seg_end, limit, data_end, &cnt, &err);
+                const int s = sb + k;
+                const long long l64 = hop(buf, (long long)c32, (long long)seg_end, limit, data_end, &cnt, &err);
                 if (err) { error = 1; stop = true; break; }
+                land = (uint32_t)l64;
                 ++fixups;
-                if (lane == 0) { seg_first[s] = cur; seg_land[s] = land; seg_count[s] = cnt; }
+                if (lane == 0) { seg_first[s] = (long long)c32; seg_land[s] = l64; seg_count[s] = cnt; }
             }
             if (lane == k) { base_l = total; visited_l = true; }
             total += cnt;
-            cur = land;
-            if (cur >= limit) { done = 1; stop = true; break; }
-            if (cur < seg_end) { stop = true; break; }   // stopped inside its segment: an incomplete record starts here
+            c32 = land;
+            if (c32 >= lim32) { done = 1; stop = true; break; }
+            if (c32 < seg_end || (unsigned long long)c32 + 4 > (unsigned long long)data_end) { stop = true; break; }   // stopped inside its segment: an incomplete record starts here
         }
         if (visited_l) { seg_base[sl] = base_l; seg_valid[sl] = 1; }
     }
+    cur = (long long)c32;
     if (lane == 0) {
         result[0] = total; result[1] = cur; result[2] = done; result[3] = error; result[4] = fixups; result[5] = first_start;
     }
@@ -1379,7 +1387,7 @@ bool launch_inflate(GpuDecoder *G, int kb, const BatchInfo &bi) {
     // LDS: they overlap well).  The batch slot's block table, CRCs and status words are free again when ev_crc fires: the
     // feeder waits for it before it re-stages the slot, the caller before it reads the status words.
     HIP_LAUNCH_OK(hipStreamWaitEvent(G->s_crc, G->ev_infl[slot], 0), "hipStreamWaitEvent");
-    hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)((bi.n_blocks + 3) / 4)), dim3(256), 0, G->s_crc, G->d_infl[slot] + CARRY_CAP, G->d_desc[slot], G->d_crc[slot],
+    hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)bi.n_blocks), dim3(WAVE), 0, G->s_crc, G->d_infl[slot] + CARRY_CAP, G->d_desc[slot], G->d_crc[slot],
                        bi.n_blocks, G->d_status[slot]);
     HIP_LAUNCH_OK(hipGetLastError(), "k_bgzf_crc");
     HIP_LAUNCH_OK(hipEventRecord(G->ev_crc[slot], G->s_crc), "hipEventRecord");
@@ -1438,13 +1446,13 @@ extern "C" int coral_bamgpu_open(const char *path, int32_t n_threads, int32_t ra
     if (rank > 0 && !find_block(G->f, G->byte_lo, &G->first_block)) G->first_block = G->f.size;
     if (G->first_block >= G->byte_hi) G->first_block = G->f.size;          // no block starts in this range: nothing to do
     G->searching = rank > 0;
-    // batch size: at most `batch_bytes` inflated, no more than the range can need.  Default 2.43 GiB = 6 x 6 656 BGZF blocks of
-    // 65 280 bytes (htslib's block size): the inflate kernel keeps 26 one-wave workgroups per CU x 256 CUs resident, blocks of
+    // batch size: at most `batch_bytes` inflated, no more than the range can need.  Default 2.52 GiB = 6 x 6 912 BGZF blocks of
+    // 65 280 bytes (htslib's block size): the inflate kernel keeps 27 one-wave workgroups per CU x 256 CUs resident, blocks of
     // equal size finish in rounds, and a batch that is a whole number of rounds has no part-filled last round; bigger batches
     // also mean fewer of them (1 GiB batches: 1.31 s for the 2 M-read file, 2.4 GiB ones: 1.13 s with the same kernel).  Offsets
     // inside a batch are 32-bit: CARRY_CAP + the batch must stay below 4 GiB.
     const uint64_t range = G->byte_hi > G->first_block ? G->byte_hi - G->first_block : 0;
-    uint64_t cap = batch_bytes > 0 ? (uint64_t)batch_bytes : 6ull * 6656ull * 65280ull;
+    uint64_t cap = batch_bytes > 0 ? (uint64_t)batch_bytes : 6ull * 6912ull * 65280ull;
     if (cap > (3ull << 30) + (512ull << 20)) cap = (3ull << 30) + (512ull << 20);
     cap = std::min<uint64_t>(cap, std::max<uint64_t>(16ull << 20, (range * 6 + (64ull << 20) + 0xffff) & ~0xffffull));
     G->infl_cap = (size_t)std::max<uint64_t>(cap, 1ull << 20);
@@ -1487,7 +1495,13 @@ extern "C" int coral_bamgpu_start(void *handle, void *workspace, int64_t workspa
         if ((e = hipEventCreateWithFlags(&G->ev_parsed[i], hipEventDisableTiming)) != hipSuccess) return bad("hipEventCreate", e);
     }
     if ((e = hipStreamCreateWithFlags(&G->s_copy, hipStreamNonBlocking)) != hipSuccess) return bad("hipStreamCreate", e);
-    if ((e = hipStreamCreateWithFlags(&G->s_infl, hipStreamNonBlocking)) != hipSuccess) return bad("hipStreamCreate", e);
+    {   // the inflate stream gets the LOWEST priority: when a batch's inflate ends, the parse kernels of that batch (caller's
+        // stream) and the next batch's inflate become runnable at the same moment; an inflate launch fills every CU with waves
+        // that run for milliseconds, and the record-start search behind it took 26 ms instead of 1.2 ms (rocprofv3 timeline)
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+        if ((e = hipStreamCreateWithPriority(&G->s_infl, hipStreamNonBlocking, least)) != hipSuccess) return bad("hipStreamCreate", e);
+    }
     if ((e = hipStreamCreateWithFlags(&G->s_crc, hipStreamNonBlocking)) != hipSuccess) return bad("hipStreamCreate", e);
     G->t_alloc = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_alloc0).count();
     G->feeder = std::thread(feeder_main, G);
@@ -1532,7 +1546,7 @@ extern "C" int coral_bamgpu_next(void *handle, int64_t out[4], void *stream_) {
     const int n_ref = (int)G->D.ref_names.size();
     long long res[6] = {0, 0, 0, 0, 0, 0};
     if (n_seg > 0) {
-        hipLaunchKernelGGL(k_bam_find, dim3((n_seg + 3) / 4), dim3(256), 0, stream, buf, begin, data_end, limit, n_ref, seg0, n_seg, G->d_seg_first,
+        hipLaunchKernelGGL(k_bam_find, dim3(n_seg), dim3(WAVE), 0, stream, buf, begin, data_end, limit, n_ref, seg0, n_seg, G->d_seg_first,
                            G->d_seg_land, G->d_seg_count, G->d_seg_valid);
         hipLaunchKernelGGL(k_bam_verify, dim3(1), dim3(WAVE), 0, stream, buf, G->searching ? -1ll : G->known_start, begin, data_end, limit, seg0, n_seg,
                            G->d_seg_first, G->d_seg_land, G->d_seg_count, G->d_seg_valid, G->d_seg_base, G->d_result);
@@ -1579,11 +1593,11 @@ extern "C" int coral_bamgpu_next(void *handle, int64_t out[4], void *stream_) {
     G->cur_n_rec = n_rec;
     G->cur_ops = G->cur_name_bytes = G->cur_sa_bytes = 0;
     if (n_rec > 0) {
-        hipLaunchKernelGGL(k_bam_starts, dim3((n_seg + 255) / 256), dim3(256), 0, stream, buf, seg0, n_seg, G->d_seg_first, G->d_seg_count, G->d_seg_valid,
+        hipLaunchKernelGGL(k_bam_starts, dim3((n_seg + WAVE - 1) / WAVE), dim3(WAVE), 0, stream, buf, seg0, n_seg, G->d_seg_first, G->d_seg_count, G->d_seg_valid,
                            G->d_seg_base, G->d_rec_start);
         (void)hipMemsetAsync(G->d_error, 0, 4, stream);
         const long long waves = n_rec + 1;
-        hipLaunchKernelGGL(k_bam_meta, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, buf, G->d_rec_start, n_rec, G->M, G->d_error);
+        hipLaunchKernelGGL(k_bam_meta, dim3((unsigned)waves), dim3(WAVE), 0, stream, buf, G->d_rec_start, n_rec, G->M, G->d_error);
         size_t tmp = G->scan_tmp_bytes;
         (void)hipcub::DeviceScan::ExclusiveSum(G->d_scan_tmp, tmp, G->M.pad_ops, G->d_cig_off, (int)(n_rec + 1), stream);
         tmp = G->scan_tmp_bytes;
@@ -1647,7 +1661,7 @@ extern "C" int coral_bamgpu_emit(void *handle, uint32_t *cigar_dst, int64_t *cig
     if (n > 0) {
         if (G->cur_ops > 0 && !cigar_dst) return CORAL_ERR_ARG;
         (void)hipMemsetAsync(G->d_na_count, 0, 4, stream);
-        hipLaunchKernelGGL(k_bam_emit, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, buf, G->d_rec_start, n, G->M, G->d_cig_off, G->d_name_off,
+        hipLaunchKernelGGL(k_bam_emit, dim3((unsigned)n), dim3(WAVE), 0, stream, buf, G->d_rec_start, n, G->M, G->d_cig_off, G->d_name_off,
                            G->d_sa_off, cigar_dst, G->d_end, G->d_qlen, G->d_names, G->d_sa_text, G->d_na_list, G->d_na_count);
         if (cigar_off_dst && hipMemcpyAsync(cigar_off_dst, G->d_cig_off, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, stream) != hipSuccess)
             return fail(CORAL_ERR_HIP, "device copy of the op offsets failed");
@@ -1710,7 +1724,7 @@ extern "C" int coral_bamgpu_emit(void *handle, uint32_t *cigar_dst, int64_t *cig
                 hipMemcpy(G->d_name_off, dst.data(), (size_t)na_count * 8, hipMemcpyHostToDevice) != hipSuccess ||
                 hipMemcpy(G->d_sa_off, len.data(), (size_t)na_count * 8, hipMemcpyHostToDevice) != hipSuccess)
                 return fail(CORAL_ERR_HIP, "upload of the non-ACGT gather list failed");
-            hipLaunchKernelGGL(k_bam_gather, dim3((unsigned)((na_count + 3) / 4)), dim3(256), 0, stream, buf, G->d_cig_off, G->d_name_off, G->d_sa_off, (int)na_count,
+            hipLaunchKernelGGL(k_bam_gather, dim3((unsigned)na_count), dim3(WAVE), 0, stream, buf, G->d_cig_off, G->d_name_off, G->d_sa_off, (int)na_count,
                                G->d_names);
             if (hipMemcpyAsync(J.na_raw.data(), G->d_names, (size_t)total, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
                 return fail(CORAL_ERR_HIP, "copy of the records with non-ACGT bases failed");

@@ -43,11 +43,14 @@ CORAL_HD uint32_t make_entry(uint32_t nbits, uint32_t kind, uint32_t extra, uint
 
 struct Tables {                      // per wave, in LDS on the device
     uint16_t ll[1 << LL_BITS];       // literal / length codes of up to LL_BITS bits, indexed by the next LL_BITS stream bits
-    uint32_t dt[1 << D_BITS];        // distance codes of up to D_BITS bits
+    union {
+        uint32_t dt[1 << D_BITS];    // distance codes of up to D_BITS bits
+        uint8_t lens[320 + 4];       // code lengths while a dynamic header is read: dead once the distance code's counts and
+    };                               // sorted symbols exist, which is before `dt` is filled (Inflater::build) — same memory
     uint32_t ll_count[16], d_count[16];      // codes per length (canonical decode of the long codes; table build)
     uint16_t ll_sym[288 + 32];       // symbols sorted by (length, symbol); [288..320) = the same for the distance code
-    uint8_t lens[320 + 4];           // code lengths while a dynamic header is read
 };
+static_assert(sizeof(Tables) == 2048 + 1024 + 128 + 640, "Tables: 3840 bytes of LDS per wave");
 
 // length symbol 257 + i -> (base, extra bits);  distance symbol d -> (base, extra bits)      (RFC 1951 §3.2.5, computed)
 CORAL_HD uint32_t ll_entry(uint32_t sym, uint32_t nbits) {

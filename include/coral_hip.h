@@ -393,7 +393,7 @@ const char *coral_bam_last_error(void);
  * rule for rank / world.  Every inflated block's CRC-32 is checked against its BGZF trailer (k_bgzf_crc), as htslib does.
  * The library allocates no device memory: the caller provides one workspace.
  *
- *   open   parse the header, size the batches (`batch_bytes` inflated bytes per batch; 0 = default 2.43 GiB, at most 3.5 GiB, never more than
+ *   open   parse the header, size the batches (`batch_bytes` inflated bytes per batch; 0 = default 2.52 GiB, at most 3.5 GiB, never more than
  *          the byte range needs) -> *workspace_bytes the caller must allocate on the current device (256-byte aligned)
  *   start  take the workspace, start reading / uploading / inflating
  *   next   parse the next batch up to its sizes: out[0] records, out[1] padded CIGAR words, out[2] 1 = a batch is pending

@@ -79,3 +79,13 @@ for k, run in enumerate(runs):
     d_inf = [(r[1] - r[0]) / 1e6 for r in run]
     P("\ninflate launches: min %.2f / median %.2f / max %.2f ms; the first five %s, the last five %s\n" % (
         min(d_inf), sorted(d_inf)[len(d_inf) // 2], max(d_inf), ["%.1f" % x for x in d_inf[:5]], ["%.1f" % x for x in d_inf[-5:]]))
+    # the parse kernels one batch at a time: (start relative to the run's first inflate, duration), and which inflate launch was
+    # running when they started — a kernel that shares the chip with an inflate launch is slower than it is alone
+    for want in ("k_bam_find", "k_bam_verify", "k_bgzf_crc"):
+        ks = sorted(r for r in inside if r[2].startswith(want))
+        if not ks:
+            continue
+        P("`%s` per batch (start ms, duration ms, [overlapping inflate: its start, duration]); first 8 and last 3:" % want)
+        for r in ks[:8] + ks[-3:]:
+            ov = [i for i in run if i[0] < r[1] and i[1] > r[0]]
+            P("  %8.1f  %6.2f   %s" % ((r[0] - t0) / 1e6, (r[1] - r[0]) / 1e6, "; ".join("inflate @%.1f %.1f ms" % ((i[0] - t0) / 1e6, (i[1] - i[0]) / 1e6) for i in ov) or "alone"))
