@@ -214,8 +214,9 @@ def main():
         out["first_build_ms"] = round(first_build_ms, 1)
         out["value_cold"] = n_reads_total / (first_build_ms * 1e-3)
         out["config"]["first_build_phase_ms"] = first_phases
-        out["config"]["host_threads"] = {"build": "1 Python thread + %s look-ahead threads of the interval search" %
-                                         os.environ.get("CORAL_SEARCH_THREADS", "6"), "decode": "see decode.host_threads"}
+        out["config"]["host_threads"] = {"build": "1 Python thread + %s look-ahead threads + %s helper threads of the interval search" %
+                                         (os.environ.get("CORAL_SEARCH_THREADS", "6"), os.environ.get("CORAL_SEARCH_HELPERS", "8")),
+                                         "decode": "see decode.host_threads"}
         out["config"]["library"] = _lib.lib().coral_version().decode()
         if h2d_ms is not None:
             out["h2d_ms"] = round(h2d_ms, 1)

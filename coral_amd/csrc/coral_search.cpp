@@ -189,6 +189,7 @@ struct BfsOut;
 
 struct Search {
     std::unique_ptr<TaskPool> pool;                       // helpers of big steps (coral_search_params: with the look-ahead threads)
+    size_t chunk_cap = 9, chunk_reads = 1000;              // stage B of a step: at most chunk_cap chunks per run, of >= chunk_reads reads
     std::shared_ptr<BfsOut> bfs;                          // result of the last coral_search_bfs
     int64_t n_reads = 0, n_rows = 0, n_ent = 0;
     const int64_t *off = nullptr, *row_read = nullptr, *read_hash = nullptr, *read_name = nullptr, *e_key = nullptr, *e_row = nullptr;
@@ -431,7 +432,7 @@ void compute_step(Search &S, Scratch &T, const int64_t key[5], StepResult &R) {
     std::vector<Chunk> chunks;
     for (size_t g = 0; g < n_runs; ++g) {
         const size_t n_ord = order_of[g].size();
-        const size_t pieces = pooled ? std::max<size_t>(1, std::min<size_t>(8, n_ord / 2000)) : 1;
+        const size_t pieces = pooled ? std::max<size_t>(1, std::min<size_t>(S.chunk_cap, n_ord / S.chunk_reads)) : 1;
         for (size_t c = 0; c < pieces; ++c) chunks.push_back(Chunk{g, n_ord * c / pieces, n_ord * (c + 1) / pieces, {}, true});
     }
     auto stage_b = [&](Chunk &ch, Scratch &sc) {
@@ -993,7 +994,13 @@ extern "C" int coral_search_params(void *h, double min_cluster_cutoff, int64_t m
     if (!S.workers.empty() || !S.cache.empty()) return CORAL_ERR_ARG;          // set once, before the first step
     S.min_cluster_cutoff = min_cluster_cutoff; S.max_seq_len = max_seq_len; S.bp_distance_cutoff = bp_distance_cutoff;
     S.match_cutoff = match_cutoff; S.accept_floor = accept_floor;
-    if (n_threads > 0) S.pool.reset(new TaskPool(3));
+    if (n_threads > 0) {
+        int helpers = 8;                                   // (CORAL_SEARCH_HELPERS, CORAL_SEARCH_CHUNK: tuning)
+        if (const char *e = getenv("CORAL_SEARCH_HELPERS")) helpers = std::max(0, std::min(15, atoi(e)));
+        if (const char *e = getenv("CORAL_SEARCH_CHUNK")) S.chunk_reads = (size_t)std::max(200, atoi(e));
+        S.chunk_cap = (size_t)std::max(8, helpers + 1);
+        if (helpers > 0) S.pool.reset(new TaskPool(helpers));
+    }
     const std::vector<int> cpus = n_threads > 0 ? cpus_of_my_node() : std::vector<int>();
     for (int32_t k = 0; k < n_threads; ++k) {
         S.workers.emplace_back(worker_main, &S);
