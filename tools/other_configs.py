@@ -1,6 +1,6 @@
 """bench lines of the other BASELINE.json configurations (gpurun_out/b_<cfg>.log) -> profiles/r03_other_configs.md"""
 import json, sys
-out = ["# Other BASELINE.json configurations on one MI355X (round 3) — `python bench.py --config <cfg> --steps 3 --warmup 1`\n",
+out = ["# Other BASELINE.json configurations on one MI355X (round 3) — `python bench.py --config <cfg> --steps 10 --warmup 3 --bam-reads -1`\n",
        "Parity for these configurations is tested against the oracle / goldens on subsamples (`tests/`); these lines are throughput only.\n",
        "| config | workload | reads/s | ms/step | scan launch ms | roofline frac | CPU port reads/s (sample) |", "|---|---|---|---|---|---|---|"]
 lines = []
