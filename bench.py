@@ -215,7 +215,7 @@ def main():
         out["value_cold"] = n_reads_total / (first_build_ms * 1e-3)
         out["config"]["first_build_phase_ms"] = first_phases
         out["config"]["host_threads"] = {"build": "1 Python thread + %s look-ahead threads + %s helper threads of the interval search" %
-                                         (os.environ.get("CORAL_SEARCH_THREADS", "6"), os.environ.get("CORAL_SEARCH_HELPERS", "8")),
+                                         (os.environ.get("CORAL_SEARCH_THREADS", "6"), os.environ.get("CORAL_SEARCH_HELPERS", "8" if (os.cpu_count() or 1) >= 16 else "3" if (os.cpu_count() or 1) >= 8 else "1")),
                                          "decode": "see decode.host_threads"}
         out["config"]["library"] = _lib.lib().coral_version().decode()
         if h2d_ms is not None:

@@ -995,7 +995,9 @@ extern "C" int coral_search_params(void *h, double min_cluster_cutoff, int64_t m
     S.min_cluster_cutoff = min_cluster_cutoff; S.max_seq_len = max_seq_len; S.bp_distance_cutoff = bp_distance_cutoff;
     S.match_cutoff = match_cutoff; S.accept_floor = accept_floor;
     if (n_threads > 0) {
-        int helpers = 8;                                   // (CORAL_SEARCH_HELPERS, CORAL_SEARCH_CHUNK: tuning)
+        // 8 helpers where the cores are there (with the look-ahead threads and the caller: 15 threads); fewer on small hosts
+        const unsigned hw = std::thread::hardware_concurrency();
+        int helpers = hw >= 16 ? 8 : hw >= 8 ? 3 : 1;      // (CORAL_SEARCH_HELPERS, CORAL_SEARCH_CHUNK: tuning)
         if (const char *e = getenv("CORAL_SEARCH_HELPERS")) helpers = std::max(0, std::min(15, atoi(e)));
         if (const char *e = getenv("CORAL_SEARCH_CHUNK")) S.chunk_reads = (size_t)std::max(200, atoi(e));
         S.chunk_cap = (size_t)std::max(8, helpers + 1);
